@@ -1,0 +1,190 @@
+/*
+ * moviigen_hip.h — C-ABI of libmoviigen_hip.so, the MI355X (gfx950) kernels behind the
+ * MoviiGen1.1 / Wan2.1-14B T2V denoising hot path.
+ *
+ * The reference (ZulutionAI/MoviiGen1.1) is pure Python + torch and has no FFI of its own;
+ * every arithmetic step of its hot path is a call into a third-party native kernel
+ * (cuBLAS / flash_attn / ATen elementwise / cuDNN).  Each entry point below names the
+ * reference call site (file:line under the reference tree) whose arithmetic it replaces.
+ * The Python side that binds these with ctypes is moviigen1.1_amd/wan/backend/lib.py; the
+ * binding a reference maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns 0 (MG_OK) or a negative error code; nothing throws, nothing
+ *     allocates, nothing synchronises: work is enqueued on `stream` (a hipStream_t passed as
+ *     void*; NULL = the legacy default stream).
+ *   - all pointers are DEVICE pointers owned by the caller.  bf16 travels as uint16_t.
+ *   - `ld*` arguments are row strides in ELEMENTS.  Row-major everywhere.
+ *   - no torch types, no C++ types in any signature.
+ */
+#ifndef MOVIIGEN_HIP_H
+#define MOVIIGEN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MG_OK 0
+#define MG_ERR_ARG (-1)    /* null pointer / bad enum */
+#define MG_ERR_SHAPE (-2)  /* unsupported shape or alignment */
+#define MG_ERR_LAUNCH (-3) /* hipGetLastError() != hipSuccess after launch */
+
+/* library identification: returns a static string "moviigen_hip <abi> gfx950" */
+const char* mg_version(void);
+/* ABI revision, bumped on any signature change */
+int mg_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * DiT — token-wise HBM-bound kernels
+ * ---------------------------------------------------------------------------------------- */
+
+/* WanLayerNorm (eps, no affine) in fp32 followed by the AdaLN modulation, or by an affine
+ * weight/bias (norm3).  Replaces wan/modules/model.py:89-99 + :299,:307 (norm1/norm2 +
+ * `*(1+scale)+shift`), :306 (norm3, elementwise_affine) and :340-342 (head norm+modulate).
+ *   y = (x-mean)*rsqrt(var+eps);  if round_norm_bf16: y = bf16(y)   [block 0: x is bf16 there,
+ *   model.py:99 `.type_as(x)`];  out = add_one ? y*(1+scale)+shift : y*scale+shift
+ *   scale/shift: fp32 [dim] or NULL (=> 1 / 0).  out: bf16 (out_f32=0) or fp32 (out_f32=1).
+ * dim % 4 == 0, dim <= 8192. */
+int mg_ln_modulate(const float* x, int64_t ldx, int64_t rows, int dim, const float* scale,
+                   const float* shift, int add_one, float eps, int round_norm_bf16, void* out,
+                   int out_f32, int64_t ldo, void* stream);
+
+/* WanRMSNorm over the whole `dim` vector (fp32 math, result rounded to bf16, then * weight in
+ * fp32) and optional 3-axis RoPE on adjacent pairs, output bf16.
+ * Replaces wan/modules/model.py:70-86 (+:139-140, :168-169) and rope_apply model.py:39-67 /
+ * wan/distributed/xdit_context_parallel.py:23-62 (rank slice = pos0).
+ *   rope_cs: NULL (no RoPE: cross-attention q/k) or float2 (cos,sin) tables laid out as
+ *            [F][c0] ++ [H][c1] ++ [W][c1] with c = head_dim/2, c1 = c/3, c0 = c - 2*c1
+ *   token index of row r is pos0 + r, decomposed (f,h,w) row-major over the F*H*W grid;
+ *   rows with token index >= F*H*W are passed through un-rotated (padding, model.py:61).
+ * dim % 8 == 0, dim <= 8192, head_dim % 2 == 0, dim % head_dim == 0, ldx/ldo % 8 == 0. */
+int mg_rmsnorm_rope_bf16(const uint16_t* x, int64_t ldx, uint16_t* out, int64_t ldo,
+                         int64_t rows, int dim, const float* weight, float eps, int head_dim,
+                         const float* rope_cs, int F, int H, int W, int64_t pos0, void* stream);
+
+/* v [L][heads*head_dim] (row stride ldv) -> vt [heads][head_dim][Lpad], zero-filled for keys
+ * in [L, Lpad).  Layout contract of mg_attn_fwd_bf16_hd128 (keys contiguous for the P.V MFMA
+ * A-operand); no reference counterpart (flash_attn hides its own V staging).
+ * head_dim == 128, Lpad % 64 == 0, Lpad >= L. */
+int mg_transpose_v_bf16(const uint16_t* v, int64_t ldv, int64_t L, int heads, int head_dim,
+                        uint16_t* vt, int64_t Lpad, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * DiT — MFMA kernels
+ * ---------------------------------------------------------------------------------------- */
+
+enum {
+    MG_EPI_BIAS_BF16 = 0,      /* out_bf16 = bf16(acc + bias)                         nn.Linear */
+    MG_EPI_BIAS_GELU_BF16 = 1, /* out_bf16 = bf16(gelu_tanh(bf16(acc + bias)))        ffn.0+ffn.1 */
+    MG_EPI_GATE_RESID_F32 = 2, /* out_f32 += bf16(acc + bias) * gate[n] (gate NULL=>1) x + y*e */
+    MG_EPI_BIAS_F32 = 3        /* out_f32 = float(bf16(acc + bias))                   patch embed */
+};
+
+/* out[M][N] = A[M][K] . W[N][K]^T (+bias, epilogue) — bf16 operands, fp32 MFMA accumulate
+ * (v_mfma_f32_32x32x16_bf16).  Replaces every nn.Linear executed under autocast(bf16) on the
+ * path: wan/modules/model.py:139-141,155 (q,k,v,o), :168-170,180 (cross q,k,v,o), :267-269
+ * (ffn), :451-453 (text_embedding), :445-450 (patch_embedding as a [L,64]x[64,dim] GEMM), with
+ * the residual/gate updates of model.py:301-302,306,308-309 fused as epilogue 2.
+ * K % 64 == 0, lda/ldw % 8 == 0, A/W 16-byte aligned; ldo % 4 == 0. */
+int mg_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw,
+                 const float* bias, int64_t M, int N, int K, int epilogue, void* out,
+                 int64_t ldo, const float* gate, void* stream);
+
+/* softmax(q k^T * scale) v, non-causal, keys >= Lk masked; bf16 in/out, fp32 accumulate,
+ * head_dim 128.  Replaces flash_attn_varlen_func as called from
+ * wan/modules/attention.py:96-127 (self-attention model.py:146-151, k_lens=seq_lens;
+ * cross-attention model.py:176, Lk = 512 unmasked).
+ *   q [Lq][>=heads*128] row stride ldq; k [Lk][..] row stride ldk; head h at column h*128
+ *   vt [heads][128][ldvt] from mg_transpose_v_bf16 (ldvt % 64 == 0, ldvt >= Lk, zero padded)
+ *   o [Lq][..] row stride ldo. */
+int mg_attn_fwd_bf16_hd128(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk,
+                           const uint16_t* vt, int64_t ldvt, uint16_t* o, int64_t ldo,
+                           int64_t Lq, int64_t Lk, int heads, float scale, void* stream);
+
+/* Tuning knob: 1 (default) = defer the online-softmax rescale while no row maximum grew by more
+ * than 2^8 since the last rescale (P <= 256 in bf16); 0 = rescale every tile. */
+void mg_attn_set_lazy_rescale(int on);
+
+/* ------------------------------------------------------------------------------------------
+ * DiT — small fp32 pieces (time embedding, head, patch gather, latent algebra)
+ * ---------------------------------------------------------------------------------------- */
+
+/* sinusoidal_embedding_1d, wan/modules/model.py:15-25: out[i][0:half]=cos(t_i*w_j),
+ * out[i][half:]=sin(..), w_j = 10000^(-j/half), evaluated in fp64, stored fp32.
+ * t_dtype: 0 = int64, 1 = float32, 2 = float64 (device pointer, n entries). */
+int mg_sinusoid_embed(const void* t, int t_dtype, int n, int dim, float* out, void* stream);
+
+/* y[N] = W[N][K] . f(x[K]) + bias,  f = SiLU if silu_in else identity; all fp32.
+ * Replaces time_embedding / time_projection, wan/modules/model.py:455-457,541-545. */
+int mg_gemv_f32(const float* W, const float* bias, const float* x, float* y, int N, int K,
+                int silu_in, void* stream);
+
+/* out[r][:] = a[r][:] + b[r % period][:]  (modulation + e0, model.py:292-295; head :340). */
+int mg_add_rows_f32(const float* a, const float* b, float* out, int rows, int dim, int period,
+                    void* stream);
+
+/* fp32 out[M][N] = x[M][K] . W[N][K]^T + bias (Head.head Linear, model.py:342; N <= 64). */
+int mg_head_gemm_f32(const float* x, int64_t ldx, const float* W, const float* bias, float* out,
+                     int64_t M, int N, int K, void* stream);
+
+/* latent [C][F][H][W] fp32 -> tokens [F*(H/ph)*(W/pw)][C*ph*pw] bf16 with k = (c,i,j), the
+ * im2col of the k=s=(1,ph,pw) Conv3d at model.py:445-450,529-531. */
+int mg_patchify_bf16(const float* lat, int C, int F, int H, int W, int ph, int pw,
+                     uint16_t* out, int64_t ldo, void* stream);
+
+/* tokens [F*Hg*Wg][ph*pw*C] fp32 (channel fastest) -> latent [C][F][Hg*ph][Wg*pw];
+ * WanModel.unpatchify, model.py:581-609. */
+int mg_unpatchify_f32(const float* tok, int64_t ldt, int C, int F, int Hg, int Wg, int ph, int pw,
+                      float* lat, void* stream);
+
+/* out[i] = c0*x0[i] + c1*x1[i] + c2*x2[i] + c3*x3[i]  (NULL terms skipped).  CFG combine
+ * (wan/text2video.py:245-246) and every UniPC / DPM-Solver++ update
+ * (wan/utils/fm_solvers_unipc.py:315-332,455-485,600-627; fm_solvers.py:461-470,533-541) are
+ * linear combinations with host-side scalar coefficients. */
+int mg_lincomb4_f32(float* out, int64_t n, const float* x0, float c0, const float* x1, float c1,
+                    const float* x2, float c2, const float* x3, float c3, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * WanVAE decode (fp32, channels-last activations [T][H][W][C])
+ * ---------------------------------------------------------------------------------------- */
+
+/* Generic causal conv as an implicit GEMM on fp32 MFMA (v_mfma_f32_32x32x2_f32, exact f32).
+ * x: [T][H][W][Cin] channels-last;  w: [Cout][kt][kh][kw][Cin];  out: [T][Ho][Wo][Cout].
+ * Temporal taps reach back kt-1 frames: frame index t-(kt-1)+dt; frames < 0 come from
+ * `cache` ([tc][H][W][Cin], the last tc <= kt-1 frames of the previous chunk, may be NULL) and
+ * are zero before that (CausalConv3d, wan/modules/vae.py:17-36).  Spatial zero padding
+ * (kh/2, kw/2).  `up2`: the input is read through a nearest-exact 2x upsample (Ho=2H, Wo=2W;
+ * Resample upsample2d/3d, vae.py:66-83,138-141).  residual (same shape as out, may be NULL) is
+ * added (ResidualBlock `x + h`, vae.py:220). */
+int mg_vae_conv_f32(const float* x, const float* cache, int tc, int T, int H, int W, int Cin,
+                    const float* w, const float* bias, int Cout, int kt, int kh, int kw, int up2,
+                    const float* residual, float* out, void* stream);
+
+/* RMS_norm over channels (F.normalize(x, dim=C) * sqrt(C) * gamma, vae.py:39-54), optional SiLU
+ * (vae.py:193-197, 466-468).  x,out [rows][C] channels-last. */
+int mg_vae_rmsnorm_silu_f32(const float* x, const float* gamma, float* out, int64_t rows, int C,
+                            int do_silu, void* stream);
+
+/* Single-head attention over one frame's h*w tokens with head dim C (<=512, %32==0), fp32:
+ * AttentionBlock, vae.py:247-256 (scaled_dot_product_attention, scale 1/sqrt(C)).
+ * qkv [frames][L][3C] (q|k|v), out [frames][L][C]. */
+int mg_vae_attn_f32(const float* qkv, float* out, int frames, int64_t L, int C, void* stream);
+
+/* z[C][T][H][W] (NCTHW, reference layout) -> channels-last with the latent un-normalisation
+ * z/scale1[c] + scale0[c] of vae.py:546-551; and the inverse layout change with clamp(-1,1) for
+ * the decoded video (vae.py:661). */
+int mg_vae_latent_in_f32(const float* z, const float* mean, const float* inv_std, int C, int T,
+                         int H, int W, float* out, void* stream);
+int mg_vae_video_out_f32(const float* x, int C, int T, int H, int W, float* out, int t_off,
+                         int T_total, void* stream);
+
+/* time_conv channel halves -> interleaved frames (vae.py:133-137):
+ * x [T][H][W][2C] -> out [2T][H][W][C], frame 2t from channels [0,C), 2t+1 from [C,2C). */
+int mg_vae_time_interleave_f32(const float* x, int T, int64_t HW, int C, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOVIIGEN_HIP_H */

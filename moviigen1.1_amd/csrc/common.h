@@ -1,0 +1,73 @@
+// Shared device helpers for the MoviiGen1.1 MI355X (gfx950 / CDNA4) kernels.
+// wave = 64 lanes; bf16 travels as uint16_t; all math in fp32 unless stated.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MG_OK 0
+#define MG_ERR_ARG (-1)
+#define MG_ERR_SHAPE (-2)
+#define MG_ERR_LAUNCH (-3)
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) unsigned short u16x8_t;
+typedef __attribute__((ext_vector_type(4))) unsigned short u16x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+
+#define MG_DEV static __device__ __forceinline__
+
+// fp32 -> bf16 round-to-nearest-even (matches torch .to(bfloat16) for finite values)
+MG_DEV unsigned short f2bf(float f) {
+    unsigned int u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+MG_DEV float bf2f(unsigned short h) { return __uint_as_float(((unsigned int)h) << 16); }
+MG_DEV float round_bf(float f) { return bf2f(f2bf(f)); }
+MG_DEV unsigned int pack_bf2(float lo, float hi) {
+    return (unsigned int)f2bf(lo) | ((unsigned int)f2bf(hi) << 16);
+}
+
+MG_DEV float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+MG_DEV float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// block-wide sum for blockDim.x == NT (multiple of 64); `red` is NT/64 floats of LDS.
+template <int NT>
+MG_DEV float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __syncthreads();
+    if (l == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) t += red[i];
+    return t;
+}
+
+// torch.nn.functional.gelu(x, approximate='tanh')
+MG_DEV float gelu_tanh(float x) {
+    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+    float u = k0 * (x + k1 * x * x * x);
+    // tanh(u) = 1 - 2/(exp(2u)+1)
+    float e = __expf(2.f * u);
+    float t = 1.f - 2.f / (e + 1.f);
+    return 0.5f * x * (1.f + t);
+}
+MG_DEV float silu(float x) { return x / (1.f + __expf(-x)); }
+
+static inline int mg_check_launch() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MG_OK : MG_ERR_LAUNCH;
+}

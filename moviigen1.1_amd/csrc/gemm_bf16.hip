@@ -1,0 +1,230 @@
+// bf16 GEMM  out[M][N] = A[M][K] . W[N][K]^T  with fused epilogues, for gfx950 (CDNA4).
+//
+// Replaces every nn.Linear that the reference runs under autocast(bf16) on the DiT path
+// (wan/modules/model.py:139-141,155,168-170,180,267-269,451-453 and the k=s patch Conv3d
+// :445-450), with the residual/gate updates of model.py:301-302,306,308-309 fused.
+//
+// Design (MI355X-first, not a cuBLAS call pattern):
+//  * 128(token) x 128(feature) x 64(k) tile per 256-thread workgroup, 4 waves as 2x2, each wave a
+//    64x64 sub-tile = 2x2 v_mfma_f32_32x32x16_bf16 accumulators (64 fp32 regs/lane).
+//  * both operands are K-contiguous in HBM, so both tiles are staged with 16-byte LDS-DMA
+//    (global_load_lds_dwordx4): no VGPR round trip.  The LDS image is lane-linear per wave
+//    instruction (8 rows x 128 B); the bank-conflict swizzle is applied to the per-lane SOURCE
+//    address and undone in the ds_read_b128 address (16-B chunk c of row r lives at chunk
+//    c ^ ((r>>1)&7)), which makes every ds_read_b128 lane group hit 16 distinct 16-B slots.
+//  * double-buffered LDS (2 x 32 KiB): tile t+1 streams in while tile t is multiplied;
+//    one barrier per k-tile.  64 KiB/workgroup -> 2 workgroups per CU (8 waves).
+//  * MFMA operand roles are swapped (A-operand = W rows, B-operand = token rows) so each lane
+//    owns ONE token row and 4 consecutive output features per accumulator quad: the epilogue
+//    (bias, GELU, gate, fp32 residual read-modify-write) is row-local with 8/16-byte accesses.
+//  * workgroup ids are remapped so each XCD (private 4 MiB L2) walks a contiguous, 8-tile-tall
+//    band of the output: the concurrently resident tiles of one XCD share A and W panels.
+#include "common.h"
+#include "../../include/moviigen_hip.h"
+
+#define BM 128
+#define BN 128
+#define BK 64
+#define GEMM_THREADS 256
+#define TILE_BYTES (128 * BK * 2)  // 16 KiB per operand tile
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+MG_DEV void glds16(const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(
+    const uint16_t* __restrict__ A, int64_t lda, const uint16_t* __restrict__ Wt, int64_t ldw,
+    const float* __restrict__ bias, int64_t M, int N, int K, void* __restrict__ out, int64_t ldo,
+    const float* __restrict__ gate, int tiles_m, int tiles_n) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];  // [buf][A|W]
+
+    // ---- workgroup -> tile: XCD-contiguous remap, then 8-tall grouped raster --------------
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int GM = 8;
+    const int per_group = GM * tiles_n;
+    const int group = swz / per_group;
+    const int first_m = group * GM;
+    const int gsz = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
+    const int in_g = swz - group * per_group;
+    const int tm = first_m + in_g % gsz;
+    const int tn = in_g / gsz;
+    const int64_t m0 = (int64_t)tm * BM;
+    const int n0 = tn * BN;
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int l31 = lane & 31, g = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // ---- LDS-DMA source addresses: wave w stages rows [32w, 32w+32) of both tiles ----------
+    const int srow = lane >> 3;                        // row within the 8-row wave instruction
+    const uint16_t* ga[4];
+    const uint16_t* gw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = wave * 32 + i * 8 + srow;
+        const int cg = (lane & 7) ^ ((row >> 1) & 7);  // logical chunk stored at position lane&7
+        int64_t am = m0 + row;
+        if (am > M - 1) am = M - 1;
+        int wr = n0 + row;
+        if (wr > N - 1) wr = N - 1;
+        ga[i] = A + am * lda + cg * 8;
+        gw[i] = Wt + (int64_t)wr * ldw + cg * 8;
+    }
+    auto stage = [&](int kt, int buf) {
+        char* la = smem + buf * 2 * TILE_BYTES + wave * 32 * 128;
+        char* lw = la + TILE_BYTES;
+        const int koff = kt * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            glds16(ga[i] + koff, la + i * 8 * 128);
+            glds16(gw[i] + koff, lw + i * 8 * 128);
+        }
+    };
+
+    // ---- fragment read offsets ---------------------------------------------------------
+    const int sw = (l31 >> 1) & 7;
+    const int t3 = g ^ sw;  // chunk = t3 ^ (kk<<1)
+    const int a_row_off = (wm * 64 + l31) * 128;  // token rows (MFMA B operand)
+    const int w_row_off = (wn * 64 + l31) * 128;  // feature rows (MFMA A operand)
+
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nk = K / BK;
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+        const char* la = smem + (kt & 1) * 2 * TILE_BYTES;
+        const char* lw = la + TILE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int coff = (t3 ^ (kk << 1)) << 4;
+            bf16x8_t fa[2], fw[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                fa[j] = *(const bf16x8_t*)(la + a_row_off + j * 32 * 128 + coff);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                fw[i] = *(const bf16x8_t*)(lw + w_row_off + i * 32 * 128 + coff);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[i], fa[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: lane owns token row m, features n..n+3 per accumulator quad ---------------
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int64_t m = m0 + wm * 64 + j * 32 + l31;
+        if (m >= M) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int n = n0 + wn * 64 + i * 32 + rq * 8 + g * 4;
+                if (n >= N) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][rq * 4 + e];
+                const bool full = (n + 3 < N);
+                if (bias) {
+                    if (full) {
+                        const float4 b4 = *(const float4*)(bias + n);
+                        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (n + e < N) v[e] += bias[n + e];
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = round_bf(v[e]);  // nn.Linear output is bf16
+                if (EPI == MG_EPI_BIAS_GELU_BF16) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
+                }
+                if (EPI == MG_EPI_BIAS_BF16 || EPI == MG_EPI_BIAS_GELU_BF16) {
+                    uint16_t* o = (uint16_t*)out + m * ldo + n;
+                    if (full) {
+                        uint2 p;
+                        p.x = pack_bf2(v[0], v[1]);
+                        p.y = pack_bf2(v[2], v[3]);
+                        *(uint2*)o = p;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (n + e < N) o[e] = f2bf(v[e]);
+                    }
+                } else {
+                    float* o = (float*)out + m * ldo + n;
+                    if (EPI == MG_EPI_GATE_RESID_F32) {
+                        if (full) {
+                            float4 gg = gate ? *(const float4*)(gate + n) : make_float4(1.f, 1.f, 1.f, 1.f);
+                            float4 x4 = *(float4*)o;
+                            x4.x += v[0] * gg.x; x4.y += v[1] * gg.y; x4.z += v[2] * gg.z; x4.w += v[3] * gg.w;
+                            *(float4*)o = x4;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (n + e < N) o[e] += v[e] * (gate ? gate[n + e] : 1.f);
+                        }
+                    } else {
+                        if (full) {
+                            *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (n + e < N) o[e] = v[e];
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+extern "C" int mg_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_t ldw,
+                            const float* bias, int64_t M, int N, int K, int epilogue, void* out,
+                            int64_t ldo, const float* gate, void* stream) {
+    if (!A || !Wt || !out) return MG_ERR_ARG;
+    if (epilogue < 0 || epilogue > 3) return MG_ERR_ARG;
+    if (M < 0 || N <= 0 || K <= 0 || (K % BK) || (lda & 7) || (ldw & 7) || (ldo & 3)) return MG_ERR_SHAPE;
+    if (((uintptr_t)A & 15) || ((uintptr_t)Wt & 15) || ((uintptr_t)out & 15)) return MG_ERR_SHAPE;
+    if (bias && ((uintptr_t)bias & 15)) return MG_ERR_SHAPE;
+    if (gate && ((uintptr_t)gate & 15)) return MG_ERR_SHAPE;
+    if (M == 0) return MG_OK;
+    const int64_t tiles_m64 = (M + BM - 1) / BM;
+    const int tiles_n = (N + BN - 1) / BN;
+    if (tiles_m64 * tiles_n > 0x7fffffffLL) return MG_ERR_SHAPE;
+    const int tiles_m = (int)tiles_m64;
+    const dim3 grid((unsigned)(tiles_m * tiles_n)), block(GEMM_THREADS);
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH(E)                                                                                      \
+    hipLaunchKernelGGL(gemm_bf16_kernel<E>, grid, block, 0, st, A, lda, Wt, ldw, bias, M, N, K, out, ldo, \
+                       gate, tiles_m, tiles_n)
+    switch (epilogue) {
+        case MG_EPI_BIAS_BF16: LAUNCH(MG_EPI_BIAS_BF16); break;
+        case MG_EPI_BIAS_GELU_BF16: LAUNCH(MG_EPI_BIAS_GELU_BF16); break;
+        case MG_EPI_GATE_RESID_F32: LAUNCH(MG_EPI_GATE_RESID_F32); break;
+        default: LAUNCH(MG_EPI_BIAS_F32); break;
+    }
+#undef LAUNCH
+    return mg_check_launch();
+}

@@ -1,0 +1,481 @@
+// Standalone GPU self-test + micro-bench for libmoviigen_hip.so (no torch, no oracle import).
+// TEST INFRASTRUCTURE: each kernel is compared with a straightforward host loop written here
+// (double accumulation).  Usage:  mg_selftest [quick|full]
+//   quick: correctness at small shapes;  full: + sampled correctness and timing at 14B / 720p shapes
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "moviigen_hip.h"
+
+#define CK(x)                                                                      \
+    do {                                                                           \
+        hipError_t e_ = (x);                                                       \
+        if (e_ != hipSuccess) {                                                    \
+            printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+            exit(2);                                                               \
+        }                                                                          \
+    } while (0)
+
+static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
+static float frand() {  // uniform [-1,1)
+    rng_state = rng_state * 6364136223846793005ull + 1442695040888963407ull;
+    return (float)((rng_state >> 40) & 0xFFFFFF) / 8388608.0f - 1.0f;
+}
+static uint16_t f2bf(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static float bf2f(uint16_t h) {
+    uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+static float rbf(float f) { return bf2f(f2bf(f)); }
+
+template <typename T>
+struct Dev {
+    T* p = nullptr;
+    size_t n = 0;
+    Dev() {}
+    explicit Dev(size_t n_) : n(n_) { CK(hipMalloc(&p, n * sizeof(T))); }
+    Dev(const std::vector<T>& h) : n(h.size()) {
+        CK(hipMalloc(&p, n * sizeof(T)));
+        CK(hipMemcpy(p, h.data(), n * sizeof(T), hipMemcpyHostToDevice));
+    }
+    ~Dev() { if (p) (void)hipFree(p); }
+    std::vector<T> host() const {
+        std::vector<T> h(n);
+        CK(hipMemcpy(h.data(), p, n * sizeof(T), hipMemcpyDeviceToHost));
+        return h;
+    }
+    void zero() { CK(hipMemset(p, 0, n * sizeof(T))); }
+    Dev(const Dev&) = delete;
+    Dev& operator=(const Dev&) = delete;
+};
+
+static int n_fail = 0;
+static void report(const char* name, double err, double tol) {
+    const bool ok = (err <= tol) && !isnan(err);
+    printf("[%s] %-44s max_err=%.3e tol=%.1e\n", ok ? "PASS" : "FAIL", name, err, tol);
+    if (!ok) ++n_fail;
+    fflush(stdout);
+}
+static std::vector<float> randf(size_t n, float s = 1.f) {
+    std::vector<float> v(n);
+    for (auto& x : v) x = frand() * s;
+    return v;
+}
+static std::vector<uint16_t> randbf(size_t n, float s = 1.f) {
+    std::vector<uint16_t> v(n);
+    for (auto& x : v) x = f2bf(frand() * s);
+    return v;
+}
+static double gelu_tanh_ref(double x) {
+    return 0.5 * x * (1.0 + tanh(0.7978845608028654 * (x + 0.044715 * x * x * x)));
+}
+
+template <typename F>
+static float time_ms(F f, int iters) {
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a));
+    CK(hipEventCreate(&b));
+    f();
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a, 0));
+    for (int i = 0; i < iters; ++i) f();
+    CK(hipEventRecord(b, 0));
+    CK(hipEventSynchronize(b));
+    float ms;
+    CK(hipEventElapsedTime(&ms, a, b));
+    CK(hipEventDestroy(a));
+    CK(hipEventDestroy(b));
+    return ms / iters;
+}
+
+// ------------------------------------------------------------------------------------------------
+static void test_ln(int rows, int dim, int add_one, int round_bf, int out_f32) {
+    auto x = randf((size_t)rows * dim, 3.f), sc = randf(dim), sh = randf(dim);
+    Dev<float> dx(x), dsc(sc), dsh(sh);
+    Dev<float> of((size_t)rows * dim);
+    Dev<uint16_t> ob((size_t)rows * dim);
+    int rc = mg_ln_modulate(dx.p, dim, rows, dim, dsc.p, dsh.p, add_one, 1e-6f, round_bf,
+                            out_f32 ? (void*)of.p : (void*)ob.p, out_f32, dim, 0);
+    CK(hipDeviceSynchronize());
+    double err = rc ? 1e9 : 0;
+    auto hf = of.host();
+    auto hb = ob.host();
+    for (int r = 0; r < rows; ++r) {
+        double mean = 0, var = 0;
+        for (int c = 0; c < dim; ++c) mean += x[(size_t)r * dim + c];
+        mean /= dim;
+        for (int c = 0; c < dim; ++c) { double d = x[(size_t)r * dim + c] - mean; var += d * d; }
+        var /= dim;
+        double rstd = 1.0 / sqrt(var + 1e-6);
+        for (int c = 0; c < dim; ++c) {
+            double y = (x[(size_t)r * dim + c] - mean) * rstd;
+            if (round_bf) y = rbf((float)y);
+            double ref = y * (add_one ? 1.0 + sc[c] : sc[c]) + sh[c];
+            double got = out_f32 ? hf[(size_t)r * dim + c] : bf2f(hb[(size_t)r * dim + c]);
+            double tol_scale = out_f32 ? 1.0 : 1.0;
+            err = fmax(err, fabs(got - ref) / tol_scale);
+        }
+    }
+    char nm[128];
+    snprintf(nm, sizeof nm, "ln_modulate r%d d%d add1=%d rnd=%d f32=%d", rows, dim, add_one, round_bf, out_f32);
+    report(nm, err, out_f32 ? (round_bf ? 3e-2 : 2e-5) : 4e-2);
+}
+
+static void test_rmsnorm_rope(int rows, int dim, int hd, int F, int H, int W, int64_t pos0, bool rope) {
+    auto x = randbf((size_t)rows * dim, 2.f);
+    auto w = randf(dim);
+    const int c = hd / 2, c1 = c / 3, c0 = c - 2 * c1;
+    std::vector<float> cs((size_t)2 * (F * c0 + H * c1 + W * c1));
+    {
+        size_t o = 0;
+        auto fill = [&](int n, int cnt, int dimax) {
+            for (int p = 0; p < n; ++p)
+                for (int j = 0; j < cnt; ++j) {
+                    double fr = 1.0 / pow(10000.0, (double)(2 * j) / dimax);
+                    cs[o++] = (float)cos(p * fr);
+                    cs[o++] = (float)sin(p * fr);
+                }
+        };
+        fill(F, c0, 2 * c0);
+        fill(H, c1, 2 * c1);
+        fill(W, c1, 2 * c1);
+    }
+    Dev<uint16_t> dx(x), dout((size_t)rows * dim);
+    Dev<float> dw(w), dcs(cs);
+    int rc = mg_rmsnorm_rope_bf16(dx.p, dim, dout.p, dim, rows, dim, dw.p, 1e-6f, hd, rope ? dcs.p : nullptr,
+                                  F, H, W, pos0, 0);
+    CK(hipDeviceSynchronize());
+    auto got = dout.host();
+    double err = rc ? 1e9 : 0;
+    for (int r = 0; r < rows; ++r) {
+        double ss = 0;
+        for (int j = 0; j < dim; ++j) { double v = bf2f(x[(size_t)r * dim + j]); ss += v * v; }
+        double rr = 1.0 / sqrt(ss / dim + 1e-6);
+        int64_t tok = pos0 + r;
+        bool dr = rope && tok < (int64_t)F * H * W;
+        int pf = 0, ph = 0, pw = 0;
+        if (dr) { pf = tok / (H * W); ph = (tok % (H * W)) / W; pw = tok % W; }
+        for (int j = 0; j < dim; j += 2) {
+            double a = (double)rbf((float)(bf2f(x[(size_t)r * dim + j]) * rr)) * w[j];
+            double b = (double)rbf((float)(bf2f(x[(size_t)r * dim + j + 1]) * rr)) * w[j + 1];
+            double oa = a, ob = b;
+            if (dr) {
+                int p = (j % hd) / 2;
+                double co, si;
+                if (p < c0) { co = cs[2 * ((size_t)pf * c0 + p)]; si = cs[2 * ((size_t)pf * c0 + p) + 1]; }
+                else if (p < c0 + c1) { size_t o = (size_t)F * c0 + (size_t)ph * c1 + (p - c0); co = cs[2 * o]; si = cs[2 * o + 1]; }
+                else { size_t o = (size_t)F * c0 + (size_t)H * c1 + (size_t)pw * c1 + (p - c0 - c1); co = cs[2 * o]; si = cs[2 * o + 1]; }
+                oa = a * co - b * si;
+                ob = a * si + b * co;
+            }
+            err = fmax(err, fabs(bf2f(got[(size_t)r * dim + j]) - oa));
+            err = fmax(err, fabs(bf2f(got[(size_t)r * dim + j + 1]) - ob));
+        }
+    }
+    char nm[128];
+    snprintf(nm, sizeof nm, "rmsnorm_rope r%d d%d hd%d rope=%d pos0=%lld", rows, dim, hd, (int)rope, (long long)pos0);
+    report(nm, err, 6e-2);
+}
+
+static void test_transpose(int64_t L, int heads) {
+    const int64_t Lpad = (L + 63) / 64 * 64;
+    const int ldv = heads * 128 * 3;  // strided like a fused QKV buffer
+    auto v = randbf((size_t)L * ldv);
+    Dev<uint16_t> dv(v), dvt((size_t)heads * 128 * Lpad);
+    CK(hipMemset(dvt.p, 0xff, dvt.n * 2));
+    int rc = mg_transpose_v_bf16(dv.p + 2 * heads * 128, ldv, L, heads, 128, dvt.p, Lpad, 0);
+    CK(hipDeviceSynchronize());
+    auto got = dvt.host();
+    double err = rc ? 1e9 : 0;
+    for (int h = 0; h < heads; ++h)
+        for (int d = 0; d < 128; ++d)
+            for (int64_t kx = 0; kx < Lpad; ++kx) {
+                float ref = kx < L ? bf2f(v[(size_t)kx * ldv + 2 * heads * 128 + h * 128 + d]) : 0.f;
+                err = fmax(err, fabs(bf2f(got[((size_t)h * 128 + d) * Lpad + kx]) - ref));
+            }
+    char nm[128];
+    snprintf(nm, sizeof nm, "transpose_v L%lld heads%d", (long long)L, heads);
+    report(nm, err, 0.0);
+}
+
+// sampled GEMM check; nsamp<=0 -> full check
+static void test_gemm(int64_t M, int N, int K, int epi, int nsamp, bool timeit) {
+    auto A = randbf((size_t)M * K), Wt = randbf((size_t)N * K, 0.05f);
+    auto bias = randf(N), gate = randf(N);
+    const int64_t ldo = (N + 3) / 4 * 4;
+    std::vector<float> resid0;
+    Dev<uint16_t> dA(A), dW(Wt), ob((size_t)M * ldo);
+    Dev<float> db(bias), dg(gate), of((size_t)M * ldo);
+    if (epi == MG_EPI_GATE_RESID_F32) {
+        resid0 = randf((size_t)M * ldo);
+        CK(hipMemcpy(of.p, resid0.data(), resid0.size() * 4, hipMemcpyHostToDevice));
+    }
+    const bool f32out = epi >= 2;
+    void* outp = f32out ? (void*)of.p : (void*)ob.p;
+    int rc = mg_gemm_bf16(dA.p, K, dW.p, K, db.p, M, N, K, epi, outp, ldo, dg.p, 0);
+    CK(hipDeviceSynchronize());
+    std::vector<float> hf;
+    std::vector<uint16_t> hb;
+    if (f32out) hf = of.host(); else hb = ob.host();
+    double err = rc ? 1e9 : 0;
+    const int64_t total = M * N;
+    const int64_t cnt = nsamp > 0 ? nsamp : total;
+    for (int64_t s = 0; s < cnt; ++s) {
+        int64_t m, n;
+        if (nsamp > 0) {
+            rng_state = rng_state * 6364136223846793005ull + 1442695040888963407ull;
+            m = (int64_t)((rng_state >> 20) % (uint64_t)M);
+            n = (int)((rng_state >> 44) % (uint64_t)N);
+            if (s < 64) { m = M - 1 - (s & 7); n = N - 1 - (s >> 3); }  // exercise the edges
+        } else { m = s / N; n = s % N; }
+        double acc = 0;
+        for (int kx = 0; kx < K; ++kx) acc += (double)bf2f(A[(size_t)m * K + kx]) * bf2f(Wt[(size_t)n * K + kx]);
+        double y = rbf((float)(acc + bias[n]));
+        double ref, got;
+        if (epi == MG_EPI_BIAS_BF16) { ref = y; got = bf2f(hb[(size_t)m * ldo + n]); }
+        else if (epi == MG_EPI_BIAS_GELU_BF16) { ref = gelu_tanh_ref(y); got = bf2f(hb[(size_t)m * ldo + n]); }
+        else if (epi == MG_EPI_GATE_RESID_F32) { ref = resid0[(size_t)m * ldo + n] + y * gate[n]; got = hf[(size_t)m * ldo + n]; }
+        else { ref = y; got = hf[(size_t)m * ldo + n]; }
+        err = fmax(err, fabs(got - ref) / fmax(1.0, fabs(ref)));
+    }
+    char nm[160];
+    snprintf(nm, sizeof nm, "gemm_bf16 M%lld N%d K%d epi%d", (long long)M, N, K, epi);
+    report(nm, err, 2e-2);
+    if (timeit) {
+        float ms = time_ms([&] { mg_gemm_bf16(dA.p, K, dW.p, K, db.p, M, N, K, epi, outp, ldo, dg.p, 0); }, 5);
+        printf("    time %.3f ms  -> %.1f TFLOP/s\n", ms, 2.0 * M * N * K / (ms * 1e-3) / 1e12);
+    }
+}
+
+static void test_attn(int64_t Lq, int64_t Lk, int heads, int nsamp, bool timeit, int lazy) {
+    const int64_t ld = (int64_t)heads * 128;
+    const int64_t Lpad = (Lk + 63) / 64 * 64;
+    auto q = randbf((size_t)Lq * ld, 2.0f), k = randbf((size_t)Lk * ld, 2.0f), v = randbf((size_t)Lk * ld);
+    // make the softmax peaky for some rows: a few keys aligned with queries
+    for (int i = 0; i < 8 && i < Lk && i < Lq; ++i)
+        for (int d = 0; d < 128; ++d) k[(size_t)((i * 37) % Lk) * ld + d] = f2bf(3.f * bf2f(q[(size_t)i * ld + d]));
+    Dev<uint16_t> dq(q), dk(k), dv(v), dvt((size_t)heads * 128 * Lpad), dout((size_t)Lq * ld);
+    CK(hipMemset(dout.p, 0xff, dout.n * 2));
+    mg_attn_set_lazy_rescale(lazy);
+    int rc = mg_transpose_v_bf16(dv.p, ld, Lk, heads, 128, dvt.p, Lpad, 0);
+    const float scale = 1.f / sqrtf(128.f);
+    rc |= mg_attn_fwd_bf16_hd128(dq.p, ld, dk.p, ld, dvt.p, Lpad, dout.p, ld, Lq, Lk, heads, scale, 0);
+    CK(hipDeviceSynchronize());
+    auto got = dout.host();
+    double err = rc ? 1e9 : 0;
+    const int64_t total = Lq * heads;
+    const int64_t cnt = nsamp > 0 ? nsamp : total;
+    std::vector<double> s(Lk);
+    for (int64_t it = 0; it < cnt; ++it) {
+        int64_t qi; int h;
+        if (nsamp > 0) {
+            rng_state = rng_state * 6364136223846793005ull + 1442695040888963407ull;
+            qi = (int64_t)((rng_state >> 20) % (uint64_t)Lq);
+            h = (int)((rng_state >> 50) % (uint64_t)heads);
+            if (it < 8) qi = it;                 // the peaky rows
+            else if (it < 16) qi = Lq - 1 - (it - 8);  // tail of the last query block
+        } else { qi = it / heads; h = it % heads; }
+        double mx = -1e300;
+        for (int64_t j = 0; j < Lk; ++j) {
+            double a = 0;
+            for (int d = 0; d < 128; ++d) a += (double)bf2f(q[(size_t)qi * ld + h * 128 + d]) * bf2f(k[(size_t)j * ld + h * 128 + d]);
+            s[j] = a * scale;
+            mx = fmax(mx, s[j]);
+        }
+        double den = 0;
+        for (int64_t j = 0; j < Lk; ++j) { s[j] = exp(s[j] - mx); den += s[j]; }
+        for (int d = 0; d < 128; ++d) {
+            double a = 0;
+            for (int64_t j = 0; j < Lk; ++j) a += s[j] * bf2f(v[(size_t)j * ld + h * 128 + d]);
+            a /= den;
+            err = fmax(err, fabs(bf2f(got[(size_t)qi * ld + h * 128 + d]) - a));
+        }
+    }
+    char nm[160];
+    snprintf(nm, sizeof nm, "attn_fwd Lq%lld Lk%lld heads%d lazy%d", (long long)Lq, (long long)Lk, heads, lazy);
+    report(nm, err, 2e-2);
+    if (timeit) {
+        float ms = time_ms([&] { mg_attn_fwd_bf16_hd128(dq.p, ld, dk.p, ld, dvt.p, Lpad, dout.p, ld, Lq, Lk, heads, scale, 0); }, 3);
+        printf("    time %.3f ms  -> %.1f TFLOP/s\n", ms, 4.0 * Lq * Lk * 128 * heads / (ms * 1e-3) / 1e12);
+        float mt = time_ms([&] { mg_transpose_v_bf16(dv.p, ld, Lk, heads, 128, dvt.p, Lpad, 0); }, 3);
+        printf("    transpose_v %.3f ms\n", mt);
+    }
+}
+
+static void test_small() {
+    {  // sinusoid
+        std::vector<int64_t> t = {999, 500, 3};
+        Dev<int64_t> dt(t);
+        Dev<float> o(3 * 256);
+        int rc = mg_sinusoid_embed(dt.p, 0, 3, 256, o.p, 0);
+        CK(hipDeviceSynchronize());
+        auto h = o.host();
+        double err = rc ? 1e9 : 0;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 128; ++j) {
+                double a = (double)t[i] * pow(10000.0, -(double)j / 128);
+                err = fmax(err, fabs(h[i * 256 + j] - cos(a)));
+                err = fmax(err, fabs(h[i * 256 + 128 + j] - sin(a)));
+            }
+        report("sinusoid_embed", err, 1e-6);
+    }
+    {  // gemv
+        const int N = 777, K = 5120;
+        auto W = randf((size_t)N * K, 0.02f), b = randf(N), x = randf(K);
+        Dev<float> dW(W), db(b), dx(x), dy(N);
+        for (int silu = 0; silu < 2; ++silu) {
+            int rc = mg_gemv_f32(dW.p, db.p, dx.p, dy.p, N, K, silu, 0);
+            CK(hipDeviceSynchronize());
+            auto y = dy.host();
+            double err = rc ? 1e9 : 0;
+            for (int n = 0; n < N; ++n) {
+                double a = b[n];
+                for (int kx = 0; kx < K; ++kx) { double xv = x[kx]; if (silu) xv = xv / (1 + exp(-xv)); a += (double)W[(size_t)n * K + kx] * xv; }
+                err = fmax(err, fabs(y[n] - a));
+            }
+            report(silu ? "gemv_f32 silu_in" : "gemv_f32", err, 2e-5);
+        }
+    }
+    {  // add_rows
+        const int R = 12, D = 128;
+        auto a = randf(R * D), b = randf(6 * D);
+        Dev<float> da(a), db(b), dout(R * D);
+        int rc = mg_add_rows_f32(da.p, db.p, dout.p, R, D, 6, 0);
+        CK(hipDeviceSynchronize());
+        auto o = dout.host();
+        double err = rc ? 1e9 : 0;
+        for (int r = 0; r < R; ++r) for (int c = 0; c < D; ++c) err = fmax(err, fabs(o[r * D + c] - (a[r * D + c] + b[(r % 6) * D + c])));
+        report("add_rows_f32", err, 0);
+    }
+    {  // head gemm
+        const int64_t M = 333; const int N = 64, K = 5120;
+        auto x = randf((size_t)M * K), W = randf((size_t)N * K, 0.02f), b = randf(N);
+        Dev<float> dx(x), dW(W), db(b), dout((size_t)M * N);
+        int rc = mg_head_gemm_f32(dx.p, K, dW.p, db.p, dout.p, M, N, K, 0);
+        CK(hipDeviceSynchronize());
+        auto o = dout.host();
+        double err = rc ? 1e9 : 0;
+        for (int64_t m = 0; m < M; ++m) for (int n = 0; n < N; ++n) {
+            double a = b[n];
+            for (int kx = 0; kx < K; ++kx) a += (double)x[(size_t)m * K + kx] * W[(size_t)n * K + kx];
+            err = fmax(err, fabs(o[(size_t)m * N + n] - a));
+        }
+        report("head_gemm_f32 M333 N64 K5120", err, 1e-4);
+    }
+    {  // patchify / unpatchify
+        const int C = 16, F = 3, H = 8, W = 12, ph = 2, pw = 2;
+        auto lat = randf((size_t)C * F * H * W);
+        const int Hg = H / ph, Wg = W / pw, Kd = C * ph * pw; const int64_t L = (int64_t)F * Hg * Wg;
+        Dev<float> dl(lat); Dev<uint16_t> dt((size_t)L * Kd);
+        int rc = mg_patchify_bf16(dl.p, C, F, H, W, ph, pw, dt.p, Kd, 0);
+        CK(hipDeviceSynchronize());
+        auto t = dt.host();
+        double err = rc ? 1e9 : 0;
+        for (int64_t tok = 0; tok < L; ++tok) for (int kx = 0; kx < Kd; ++kx) {
+            int c = kx / (ph * pw), ii = (kx % (ph * pw)) / pw, jj = kx % pw;
+            int f = tok / (Hg * Wg), hg = (tok % (Hg * Wg)) / Wg, wg = tok % Wg;
+            float ref = rbf(lat[(((size_t)c * F + f) * H + hg * ph + ii) * W + wg * pw + jj]);
+            err = fmax(err, fabs(bf2f(t[(size_t)tok * Kd + kx]) - ref));
+        }
+        report("patchify_bf16", err, 0);
+        auto tokf = randf((size_t)L * Kd);
+        Dev<float> dtf(tokf), dlat((size_t)C * F * H * W);
+        rc = mg_unpatchify_f32(dtf.p, Kd, C, F, Hg, Wg, ph, pw, dlat.p, 0);
+        CK(hipDeviceSynchronize());
+        auto lo = dlat.host();
+        err = rc ? 1e9 : 0;
+        for (int c = 0; c < C; ++c) for (int f = 0; f < F; ++f) for (int h = 0; h < H; ++h) for (int w = 0; w < W; ++w) {
+            int64_t tok = ((int64_t)f * Hg + h / ph) * Wg + w / pw;
+            float ref = tokf[(size_t)tok * Kd + ((h % ph) * pw + (w % pw)) * C + c];
+            err = fmax(err, fabs(lo[(((size_t)c * F + f) * H + h) * W + w] - ref));
+        }
+        report("unpatchify_f32", err, 0);
+    }
+    {  // lincomb
+        const int64_t n = 100003;
+        auto a = randf(n), b = randf(n), c = randf(n);
+        Dev<float> da(a), db(b), dc(c), dout(n);
+        int rc = mg_lincomb4_f32(dout.p, n, da.p, 0.5f, db.p, -2.f, nullptr, 0.f, dc.p, 3.f, 0);
+        CK(hipDeviceSynchronize());
+        auto o = dout.host();
+        double err = rc ? 1e9 : 0;
+        for (int64_t i = 0; i < n; ++i) err = fmax(err, fabs(o[i] - (0.5 * a[i] - 2.0 * b[i] + 3.0 * c[i])));
+        report("lincomb4_f32", err, 2e-6);
+    }
+}
+
+static void bench_elementwise(int64_t L, int dim) {
+    Dev<float> x((size_t)L * dim), sc(dim), sh(dim);
+    Dev<uint16_t> o((size_t)L * dim), qkv((size_t)L * dim * 3), q2((size_t)L * dim);
+    Dev<float> w(dim);
+    x.zero(); sc.zero(); sh.zero(); w.zero(); qkv.zero();
+    float ms = time_ms([&] { mg_ln_modulate(x.p, dim, L, dim, sc.p, sh.p, 1, 1e-6f, 0, o.p, 0, dim, 0); }, 5);
+    printf("    ln_modulate L=%lld: %.3f ms  %.2f TB/s\n", (long long)L, ms, (double)L * dim * 6 / (ms * 1e-3) / 1e12);
+    const int c = 64, c1 = 21, c0 = 22;
+    const int F = 21, H = 45, W = 80;
+    Dev<float> cs((size_t)2 * (F * c0 + H * c1 + W * c1));
+    cs.zero();
+    (void)c;
+    ms = time_ms([&] { mg_rmsnorm_rope_bf16(qkv.p, 3 * dim, q2.p, dim, L, dim, w.p, 1e-6f, 128, cs.p, F, H, W, 0, 0); }, 5);
+    printf("    rmsnorm_rope L=%lld: %.3f ms  %.2f TB/s\n", (long long)L, ms, (double)L * dim * 4 / (ms * 1e-3) / 1e12);
+}
+
+int main(int argc, char** argv) {
+    const bool full = argc > 1 && !strcmp(argv[1], "full");
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, 0));
+    printf("device: %s  CUs=%d  %s  abi=%d\n", prop.name, prop.multiProcessorCount, mg_version(), mg_abi_version());
+
+    test_small();
+    test_ln(37, 5120, 1, 0, 0);
+    test_ln(37, 5120, 0, 0, 1);
+    test_ln(5, 128, 1, 1, 0);
+    test_ln(9, 8192, 1, 0, 1);
+    test_rmsnorm_rope(60, 5120, 128, 2, 5, 5, 0, true);   // rows 50..59 are padding tokens
+    test_rmsnorm_rope(25, 5120, 128, 2, 5, 5, 25, true);  // SP rank slice
+    test_rmsnorm_rope(17, 128, 32, 1, 4, 4, 0, true);
+    test_rmsnorm_rope(33, 5120, 128, 1, 1, 1, 0, false);
+    test_transpose(300, 2);
+    test_transpose(64, 1);
+
+    for (int epi = 0; epi < 4; ++epi) test_gemm(300, 256, 128, epi, 0, false);
+    test_gemm(128, 128, 64, 0, 0, false);
+    test_gemm(129, 200, 192, 0, 0, false);   // M and N edges
+    test_gemm(77, 64, 5120, 3, 0, false);    // head-like narrow N
+    test_gemm(1000, 1280, 1024, 2, 0, false);  // many tiles -> raster / XCD remap
+
+    test_attn(300, 300, 2, 0, false, 0);
+    test_attn(300, 300, 2, 0, false, 1);
+    test_attn(700, 512, 3, 0, false, 1);   // cross-attention shape
+    test_attn(64, 64, 1, 0, false, 1);
+    test_attn(1000, 77, 1, 0, false, 1);   // short, ragged key length
+
+    if (full) {
+        printf("---- 14B / 720p shapes (L=75600, d=5120, ffn=13824) ----\n");
+        const int64_t L = 75600;
+        bench_elementwise(L, 5120);
+        test_gemm(L, 5120, 5120, 0, 256, true);
+        test_gemm(L, 15360, 5120, 0, 256, true);
+        test_gemm(L, 13824, 5120, 1, 256, true);
+        test_gemm(L, 5120, 13824, 2, 256, true);
+        test_gemm(4096, 4096, 4096, 0, 256, true);
+        test_gemm(8192, 8192, 8192, 0, 256, true);
+        test_attn(L, 512, 40, 48, true, 1);
+        test_attn(8192, 8192, 40, 48, true, 1);
+        test_attn(L, L, 40, 40, true, 1);
+        test_attn(L, L, 40, 24, true, 0);
+    }
+    printf("%s: %d failure(s)\n", n_fail ? "SELFTEST FAILED" : "SELFTEST OK", n_fail);
+    return n_fail ? 1 : 0;
+}
