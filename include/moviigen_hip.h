@@ -103,6 +103,13 @@ int mg_attn_fwd_bf16_hd128(const uint16_t* q, int64_t ldq, const uint16_t* k, in
                            const uint16_t* vt, int64_t ldvt, uint16_t* o, int64_t ldo,
                            int64_t Lq, int64_t Lk, int heads, float scale, void* stream);
 
+/* Same contract for any head_dim <= 256 (head_dim % 8 == 0): the correctness path for model
+ * sizes whose head_dim is not 128 (BASELINE.json configs[0]: head_dim 32).  v is NOT transposed:
+ * v [Lk][>=heads*head_dim] row stride ldv. */
+int mg_attn_fwd_bf16_generic(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk,
+                             const uint16_t* v, int64_t ldv, uint16_t* o, int64_t ldo, int64_t Lq,
+                             int64_t Lk, int heads, int head_dim, float scale, void* stream);
+
 /* Tuning knob: 1 (default) = defer the online-softmax rescale while no row maximum grew by more
  * than 2^8 since the last rescale (P <= 256 in bf16); 0 = rescale every tile. */
 void mg_attn_set_lazy_rescale(int on);
@@ -146,6 +153,11 @@ int mg_unpatchify_f32(const float* tok, int64_t ldt, int C, int F, int Hg, int W
 int mg_lincomb4_f32(float* out, int64_t n, const float* x0, float c0, const float* x1, float c1,
                     const float* x2, float c2, const float* x3, float c3, void* stream);
 
+/* Classifier-free guidance in the reference's operation order: out = uncond + g*(cond - uncond)
+ * (wan/text2video.py:245-246). */
+int mg_cfg_combine_f32(float* out, const float* uncond, const float* cond, float guide_scale,
+                       int64_t n, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * WanVAE decode (fp32, channels-last activations [T][H][W][C])
  * ---------------------------------------------------------------------------------------- */
@@ -169,8 +181,10 @@ int mg_vae_rmsnorm_silu_f32(const float* x, const float* gamma, float* out, int6
 
 /* Single-head attention over one frame's h*w tokens with head dim C (<=512, %32==0), fp32:
  * AttentionBlock, vae.py:247-256 (scaled_dot_product_attention, scale 1/sqrt(C)).
- * qkv [frames][L][3C] (q|k|v), out [frames][L][C]. */
-int mg_vae_attn_f32(const float* qkv, float* out, int frames, int64_t L, int C, void* stream);
+ * qkv [frames][L][3C] (q|k|v), out [frames][L][C]; workspace: caller-owned L*L + C*L floats
+ * (the library never allocates).  L % 4 == 0. */
+int mg_vae_attn_f32(const float* qkv, float* out, int frames, int64_t L, int C, float* workspace,
+                    void* stream);
 
 /* z[C][T][H][W] (NCTHW, reference layout) -> channels-last with the latent un-normalisation
  * z/scale1[c] + scale0[c] of vae.py:546-551; and the inverse layout change with clamp(-1,1) for

@@ -1,0 +1,391 @@
+// WanVAE decode kernels, fp32-exact mode, for gfx950.
+//
+// The reference runs the whole VAE in fp32 (wan/modules/vae.py:623,658): 1.1 PFLOP of 3x3x3
+// causal convolutions at 1920x832x81.  gfx950 has an exact-f32 MFMA (v_mfma_f32_32x32x2_f32,
+// bitwise an fmaf chain) at the f32 vector peak (157 TF) — so the convolutions run as an
+// IMPLICIT GEMM on that instruction: M = output voxels, N = Cout, K = taps x Cin.
+//
+// Layout: activations are channels-last [T][H][W][C] (the reference is NCTHW): every tap of every
+// voxel is then a K-contiguous run of Cin floats, exactly like a GEMM row, and the output row of
+// a voxel is N-contiguous.  Weights are repacked once to [Cout][kt][kh][kw][Cin].
+//
+// Tile: 128 voxels x (32*NB) couts x 32 channels per step, 4 waves, wave w owns voxels
+// [32w,32w+32) x all NB cout blocks (NB x f32x16 accumulators).  MFMA A-operand = weights
+// (row = cout), B-operand = voxels, so a lane owns ONE voxel and 4 consecutive couts per
+// accumulator quad: bias + residual + store are 16-byte row-local accesses.
+// LDS rows are 36 floats (144 B): 16-byte aligned for ds_write_b128 staging and conflict-free
+// for the ds_read_b128 fragment reads (row*36 mod 64 hits 16 distinct 4-bank groups).
+// Each lane reads 4 consecutive k per ds_read_b128 and feeds them to 4 successive MFMAs; A and B
+// use the same k permutation so the contraction is complete.
+// The causal temporal padding (2 frames of cache / zeros, vae.py:28-36), the spatial zero padding
+// and the nearest-exact 2x upsample of Resample (vae.py:66-83) are all folded into the gather of
+// the A tile: no padded or upsampled tensor is ever materialised.
+#include "common.h"
+#include "../../include/moviigen_hip.h"
+
+#define CV_THREADS 256
+#define CV_BM 128
+#define CV_BK 32
+#define CV_LDS 36  // floats per LDS row
+
+struct ConvArgs {
+    const float* x; const float* cache; int tc; int T, H, W, Cin; int64_t ldx;
+    const float* w; int64_t ldw; const float* bias; int Cout; int kt, kh, kw; int up2;
+    const float* residual; float* out; int64_t ldo; int Ho, Wo; int64_t M; float out_scale;
+};
+
+template <int NB>
+__global__ __launch_bounds__(CV_THREADS) void vae_conv_kernel(const ConvArgs a) {
+    constexpr int BN = 32 * NB;
+    __shared__ __attribute__((aligned(16))) float smem[2 * (CV_BM + BN) * CV_LDS];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, l31 = lane & 31, g = lane >> 5;
+    const int64_t m0 = (int64_t)blockIdx.x * CV_BM;
+    const int n0 = blockIdx.y * BN;
+
+    // ---- gather bookkeeping: this thread stages rows (tid>>3)+32i, float4 column tid&7 -----------
+    const int ch4 = tid & 7;
+    int vt_[4], vy_[4], vx_[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t m = m0 + (tid >> 3) + 32 * i;
+        if (m < a.M) {
+            const int64_t hw = (int64_t)a.Ho * a.Wo;
+            vt_[i] = (int)(m / hw);
+            const int rem = (int)(m - (int64_t)vt_[i] * hw);
+            vy_[i] = rem / a.Wo;
+            vx_[i] = rem - vy_[i] * a.Wo;
+        } else {
+            vt_[i] = -1000000; vy_[i] = 0; vx_[i] = 0;
+        }
+    }
+    const int ncc = (a.Cin + CV_BK - 1) / CV_BK;      // channel chunks per tap
+    const int ntap = a.kt * a.kh * a.kw;
+    const int nchunk = ntap * ncc;
+
+    float4 ra[4], rw[NB];
+    auto load_chunk = [&](int kc) {
+        const int tap = kc / ncc;
+        const int c = (kc - tap * ncc) * CV_BK + ch4 * 4;
+        const int dt = tap / (a.kh * a.kw);
+        const int dyx = tap - dt * a.kh * a.kw;
+        const int dy = dyx / a.kw, dx = dyx - dy * a.kw;
+        const bool c_ok = c < a.Cin;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int ti = vt_[i] + dt - (a.kt - 1);
+            int yy = vy_[i] + dy - a.kh / 2, xx = vx_[i] + dx - a.kw / 2;
+            if (c_ok && vt_[i] >= 0 && yy >= 0 && yy < a.Ho && xx >= 0 && xx < a.Wo) {
+                if (a.up2) { yy >>= 1; xx >>= 1; }
+                const float* src = nullptr;
+                if (ti >= 0) src = a.x + (((int64_t)ti * a.H + yy) * a.W + xx) * a.ldx;
+                else if (a.tc + ti >= 0) src = a.cache + (((int64_t)(a.tc + ti) * a.H + yy) * a.W + xx) * a.ldx;
+                if (src) v = *(const float4*)(src + c);
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int row = (tid >> 3) + 32 * i;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c_ok && n0 + row < a.Cout) v = *(const float4*)(a.w + (int64_t)(n0 + row) * a.ldw + (int64_t)tap * a.Cin + c);
+            rw[i] = v;
+        }
+    };
+    auto store_chunk = [&](int buf) {
+        float* sa = smem + buf * (CV_BM + BN) * CV_LDS;
+        float* sw = sa + CV_BM * CV_LDS;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *(float4*)(sa + ((tid >> 3) + 32 * i) * CV_LDS + ch4 * 4) = ra[i];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) *(float4*)(sw + ((tid >> 3) + 32 * i) * CV_LDS + ch4 * 4) = rw[i];
+    };
+
+    f32x16_t acc[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    for (int kc = 0; kc < nchunk; ++kc) {
+        if (kc + 1 < nchunk) load_chunk(kc + 1);
+        const float* sa = smem + (kc & 1) * (CV_BM + BN) * CV_LDS + (wave * 32 + l31) * CV_LDS + g * 4;
+        const float* sw = smem + (kc & 1) * (CV_BM + BN) * CV_LDS + CV_BM * CV_LDS + l31 * CV_LDS + g * 4;
+#pragma unroll
+        for (int k8 = 0; k8 < 4; ++k8) {
+            const float4 xa = *(const float4*)(sa + k8 * 8);
+            const float xv[4] = {xa.x, xa.y, xa.z, xa.w};
+            float4 wv4[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) wv4[nb] = *(const float4*)(sw + nb * 32 * CV_LDS + k8 * 8);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const float wv = s == 0 ? wv4[nb].x : s == 1 ? wv4[nb].y : s == 2 ? wv4[nb].z : wv4[nb].w;
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv, xv[s], acc[nb], 0, 0, 0);
+                }
+            }
+        }
+        if (kc + 1 < nchunk) store_chunk((kc + 1) & 1);
+        __syncthreads();
+    }
+
+    const int64_t m = m0 + wave * 32 + l31;
+    if (m >= a.M) return;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            const int n = n0 + nb * 32 + rq * 8 + g * 4;
+            if (n >= a.Cout) continue;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[nb][rq * 4 + e] * a.out_scale;
+            if (n + 3 < a.Cout) {
+                if (a.bias) { const float4 b = *(const float4*)(a.bias + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+                if (a.residual) { const float4 r = *(const float4*)(a.residual + m * a.ldo + n); v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
+                *(float4*)(a.out + m * a.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < a.Cout) {
+                        float y = v[e];
+                        if (a.bias) y += a.bias[n + e];
+                        if (a.residual) y += a.residual[m * a.ldo + n + e];
+                        a.out[m * a.ldo + n + e] = y;
+                    }
+            }
+        }
+    }
+}
+
+static int launch_conv(const ConvArgs& a, hipStream_t st) {
+    const int64_t tiles_m = (a.M + CV_BM - 1) / CV_BM;
+    if (tiles_m > 0x7fffffffLL) return MG_ERR_SHAPE;
+    int nb;
+    if (a.Cout <= 32) nb = 1;
+    else if (a.Cout % 128 == 0) nb = 4;
+    else if (a.Cout % 96 == 0) nb = 3;
+    else nb = 4;
+    const int bn = 32 * nb;
+    const dim3 grid((unsigned)tiles_m, (unsigned)((a.Cout + bn - 1) / bn)), block(CV_THREADS);
+    if (nb == 1) hipLaunchKernelGGL(vae_conv_kernel<1>, grid, block, 0, st, a);
+    else if (nb == 3) hipLaunchKernelGGL(vae_conv_kernel<3>, grid, block, 0, st, a);
+    else hipLaunchKernelGGL(vae_conv_kernel<4>, grid, block, 0, st, a);
+    return mg_check_launch();
+}
+
+extern "C" int mg_vae_conv_f32(const float* x, const float* cache, int tc, int T, int H, int W, int Cin,
+                               const float* w, const float* bias, int Cout, int kt, int kh, int kw, int up2,
+                               const float* residual, float* out, void* stream) {
+    if (!x || !w || !out) return MG_ERR_ARG;
+    if (T <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 3) || Cout <= 0 || kt < 1 || kh < 1 || kw < 1 ||
+        !(kh & 1) || !(kw & 1) || tc < 0 || tc > kt - 1 || (tc > 0 && !cache))
+        return MG_ERR_SHAPE;
+    if (((uintptr_t)x & 15) || ((uintptr_t)w & 15) || ((uintptr_t)out & 15) || (cache && ((uintptr_t)cache & 15)) ||
+        (bias && ((uintptr_t)bias & 15)) || (residual && ((uintptr_t)residual & 15)))
+        return MG_ERR_SHAPE;
+    ConvArgs a;
+    a.x = x; a.cache = cache; a.tc = tc; a.T = T; a.H = H; a.W = W; a.Cin = Cin; a.ldx = Cin;
+    a.w = w; a.ldw = (int64_t)kt * kh * kw * Cin; a.bias = bias; a.Cout = Cout; a.kt = kt; a.kh = kh; a.kw = kw;
+    a.up2 = up2 ? 1 : 0; a.residual = residual; a.out = out; a.ldo = Cout;
+    a.Ho = up2 ? 2 * H : H; a.Wo = up2 ? 2 * W : W; a.M = (int64_t)T * a.Ho * a.Wo; a.out_scale = 1.f;
+    return launch_conv(a, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// RMS_norm over channels (+ SiLU) — vae.py:39-54: F.normalize(x, dim=C) * sqrt(C) * gamma
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vae_rmsnorm_silu_kernel(const float* __restrict__ x,
+                                                               const float* __restrict__ gamma,
+                                                               float* __restrict__ out, int64_t rows, int C,
+                                                               int do_silu) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float sc = sqrtf((float)C);
+    const int nv = C >> 2;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+        const float4* xr = (const float4*)(x + row * C);
+        float4 v[2];
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = lane + 64 * i;
+            v[i] = c < nv ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            ss += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+        }
+        ss = wave_sum(ss);
+        const float inv = sc / fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+                const float4 gm = ((const float4*)gamma)[c];
+                float4 y = make_float4(v[i].x * inv * gm.x, v[i].y * inv * gm.y, v[i].z * inv * gm.z,
+                                       v[i].w * inv * gm.w);
+                if (do_silu) { y.x = silu(y.x); y.y = silu(y.y); y.z = silu(y.z); y.w = silu(y.w); }
+                ((float4*)(out + row * C))[c] = y;
+            }
+        }
+    }
+}
+
+extern "C" int mg_vae_rmsnorm_silu_f32(const float* x, const float* gamma, float* out, int64_t rows, int C,
+                                       int do_silu, void* stream) {
+    if (!x || !gamma || !out) return MG_ERR_ARG;
+    if (C <= 0 || (C & 3) || C > 512 || rows < 0) return MG_ERR_SHAPE;
+    if (rows == 0) return MG_OK;
+    int64_t g = (rows + 3) / 4;
+    if (g > 65536 * 8) g = 65536 * 8;
+    hipLaunchKernelGGL(vae_rmsnorm_silu_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, gamma,
+                       out, rows, C, do_silu);
+    return mg_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// AttentionBlock — vae.py:247-256.  S = q k^T / sqrt(C) and o = softmax(S) v as two implicit-GEMM
+// launches around a row softmax; S (L x L fp32) lives in caller workspace.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ s, int64_t L) {
+    __shared__ float red[4];
+    float* row = s + (int64_t)blockIdx.x * L;
+    float mx = -3.0e38f;
+    for (int64_t i = threadIdx.x; i < L; i += 256) mx = fmaxf(mx, row[i]);
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int64_t i = threadIdx.x; i < L; i += 256) {
+        const float e = expf(row[i] - mx);
+        row[i] = e;
+        sum += e;
+    }
+    sum = block_sum<256>(sum, red);
+    const float inv = 1.f / sum;
+    for (int64_t i = threadIdx.x; i < L; i += 256) row[i] *= inv;
+}
+
+__global__ void transpose_f32_kernel(const float* __restrict__ in, int64_t ldin, float* __restrict__ out,
+                                     int64_t rows, int cols) {
+    // in [rows][cols] (row stride ldin) -> out [cols][rows]
+    __shared__ float tile[32][33];
+    const int64_t r0 = (int64_t)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const int64_t r = r0 + i;
+        const int c = c0 + threadIdx.x;
+        tile[i][threadIdx.x] = (r < rows && c < cols) ? in[r * ldin + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const int c = c0 + i;
+        const int64_t r = r0 + threadIdx.x;
+        if (c < cols && r < rows) out[(int64_t)c * rows + r] = tile[threadIdx.x][i];
+    }
+}
+
+extern "C" int mg_vae_attn_f32(const float* qkv, float* out, int frames, int64_t L, int C, float* workspace,
+                               void* stream) {
+    if (!qkv || !out || !workspace) return MG_ERR_ARG;
+    if (frames <= 0 || L <= 0 || (L & 3) || C <= 0 || (C & 3) || L > 0x7fffffffLL) return MG_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    float* S = workspace;                 // [L][L]
+    float* vT = workspace + L * L;        // [C][L]
+    for (int f = 0; f < frames; ++f) {
+        const float* base = qkv + (int64_t)f * L * 3 * C;
+        ConvArgs a;
+        // S[L][L] = q[L][C] . k[L][C]^T * C^-1/2
+        a.x = base; a.cache = nullptr; a.tc = 0; a.T = 1; a.H = 1; a.W = (int)L; a.Cin = C; a.ldx = 3 * C;
+        a.w = base + C; a.ldw = 3 * C; a.bias = nullptr; a.Cout = (int)L; a.kt = a.kh = a.kw = 1; a.up2 = 0;
+        a.residual = nullptr; a.out = S; a.ldo = L; a.Ho = 1; a.Wo = (int)L; a.M = L;
+        a.out_scale = 1.f / sqrtf((float)C);
+        int rc = launch_conv(a, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)L), dim3(256), 0, st, S, L);
+        hipLaunchKernelGGL(transpose_f32_kernel, dim3((unsigned)((L + 31) / 32), (unsigned)((C + 31) / 32)),
+                           dim3(32, 8), 0, st, base + 2 * C, (int64_t)3 * C, vT, L, C);
+        // out[L][C] = P[L][L] . vT[C][L]^T
+        a.x = S; a.ldx = L; a.Cin = (int)L; a.w = vT; a.ldw = L; a.Cout = C; a.out = out + (int64_t)f * L * C;
+        a.ldo = C; a.out_scale = 1.f;
+        rc = launch_conv(a, st);
+        if (rc) return rc;
+    }
+    return mg_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// layout / glue kernels
+// ---------------------------------------------------------------------------------------------
+__global__ void latent_in_kernel(const float* __restrict__ z, const float* __restrict__ mean,
+                                 const float* __restrict__ inv_std, int C, int64_t thw, float* __restrict__ out) {
+    const int64_t total = thw * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int64_t v = i / C;
+        out[i] = z[(int64_t)c * thw + v] / inv_std[c] + mean[c];  // z / scale[1] + scale[0], vae.py:546-551
+    }
+}
+
+extern "C" int mg_vae_latent_in_f32(const float* z, const float* mean, const float* inv_std, int C, int T, int H,
+                                    int W, float* out, void* stream) {
+    if (!z || !mean || !inv_std || !out) return MG_ERR_ARG;
+    if (C <= 0 || T <= 0 || H <= 0 || W <= 0) return MG_ERR_SHAPE;
+    const int64_t thw = (int64_t)T * H * W;
+    int64_t g = (thw * C + 255) / 256;
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(latent_in_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, z, mean, inv_std, C,
+                       thw, out);
+    return mg_check_launch();
+}
+
+__global__ void video_out_kernel(const float* __restrict__ x, int C, int T, int64_t hw, float* __restrict__ out,
+                                 int t_off, int T_total) {
+    // x [T][HW][C] channels-last -> out[c][t_off + t][hw], clamped to [-1, 1] (vae.py:661)
+    const int64_t total = (int64_t)T * hw * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = i % hw;
+        const int64_t r = i / hw;
+        const int t = (int)(r % T), c = (int)(r / T);
+        const float v = x[((int64_t)t * hw + p) * C + c];
+        out[((int64_t)c * T_total + t_off + t) * hw + p] = fminf(1.f, fmaxf(-1.f, v));
+    }
+}
+
+extern "C" int mg_vae_video_out_f32(const float* x, int C, int T, int H, int W, float* out, int t_off, int T_total,
+                                    void* stream) {
+    if (!x || !out) return MG_ERR_ARG;
+    if (C <= 0 || T <= 0 || H <= 0 || W <= 0 || t_off < 0 || t_off + T > T_total) return MG_ERR_SHAPE;
+    const int64_t hw = (int64_t)H * W;
+    int64_t g = ((int64_t)T * hw * C + 255) / 256;
+    if (g > 16384) g = 16384;
+    hipLaunchKernelGGL(video_out_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, C, T, hw, out,
+                       t_off, T_total);
+    return mg_check_launch();
+}
+
+__global__ void time_interleave_kernel(const float* __restrict__ x, int T, int64_t hw, int C, float* __restrict__ out) {
+    // x [T][hw][2C] -> out [2T][hw][C]: frame 2t <- channels [0,C), frame 2t+1 <- [C,2C)  (vae.py:133-137)
+    const int64_t total = (int64_t)2 * T * hw * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        int64_t r = i / C;
+        const int64_t p = r % hw;
+        const int t2 = (int)(r / hw);
+        out[i] = x[(((int64_t)(t2 >> 1)) * hw + p) * 2 * C + (t2 & 1) * C + c];
+    }
+}
+
+extern "C" int mg_vae_time_interleave_f32(const float* x, int T, int64_t HW, int C, float* out, void* stream) {
+    if (!x || !out) return MG_ERR_ARG;
+    if (T <= 0 || HW <= 0 || C <= 0) return MG_ERR_SHAPE;
+    int64_t g = ((int64_t)2 * T * HW * C + 255) / 256;
+    if (g > 16384) g = 16384;
+    hipLaunchKernelGGL(time_interleave_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, T, HW, C, out);
+    return mg_check_launch();
+}

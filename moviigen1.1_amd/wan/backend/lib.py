@@ -1,0 +1,76 @@
+"""ctypes binding of libmoviigen_hip.so (C-ABI declared in include/moviigen_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a kernel returns an error
+code this module raises — it never routes to torch ops or to the oracle."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.normpath(os.path.join(_HERE, '..', '..', 'lib', 'libmoviigen_hip.so'))
+
+c_i64, c_int, c_f32, c_vp = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p
+
+# name -> argtypes (restype is int unless listed in _RESTYPE); mirrors include/moviigen_hip.h
+SIGNATURES = {
+    'mg_version': [],
+    'mg_abi_version': [],
+    'mg_ln_modulate': [c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_int, c_f32, c_int, c_vp, c_int, c_i64, c_vp],
+    'mg_rmsnorm_rope_bf16': [c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_vp, c_f32, c_int, c_vp, c_int, c_int,
+                             c_int, c_i64, c_vp],
+    'mg_transpose_v_bf16': [c_vp, c_i64, c_i64, c_int, c_int, c_vp, c_i64, c_vp],
+    'mg_gemm_bf16': [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_vp],
+    'mg_attn_fwd_bf16_hd128': [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_int, c_f32,
+                               c_vp],
+    'mg_attn_fwd_bf16_generic': [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_int, c_int,
+                                 c_f32, c_vp],
+    'mg_attn_set_lazy_rescale': [c_int],
+    'mg_sinusoid_embed': [c_vp, c_int, c_int, c_int, c_vp, c_vp],
+    'mg_gemv_f32': [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp],
+    'mg_add_rows_f32': [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp],
+    'mg_head_gemm_f32': [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp],
+    'mg_patchify_bf16': [c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_i64, c_vp],
+    'mg_unpatchify_f32': [c_vp, c_i64, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp],
+    'mg_lincomb4_f32': [c_vp, c_i64, c_vp, c_f32, c_vp, c_f32, c_vp, c_f32, c_vp, c_f32, c_vp],
+    'mg_cfg_combine_f32': [c_vp, c_vp, c_vp, c_f32, c_i64, c_vp],
+    'mg_vae_conv_f32': [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int,
+                        c_int, c_vp, c_vp, c_vp],
+    'mg_vae_rmsnorm_silu_f32': [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp],
+    'mg_vae_attn_f32': [c_vp, c_vp, c_int, c_i64, c_int, c_vp, c_vp],
+    'mg_vae_latent_in_f32': [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp],
+    'mg_vae_video_out_f32': [c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_int, c_vp],
+    'mg_vae_time_interleave_f32': [c_vp, c_int, c_i64, c_int, c_vp, c_vp],
+}
+_RESTYPE = {'mg_version': ctypes.c_char_p, 'mg_attn_set_lazy_rescale': None}
+
+ERRORS = {-1: 'MG_ERR_ARG (null pointer / bad enum)', -2: 'MG_ERR_SHAPE (unsupported shape or alignment)',
+          -3: 'MG_ERR_LAUNCH (kernel launch failed)'}
+
+_lib = None
+
+
+class MoviigenHipError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the in-tree library; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MoviigenHipError(
+            f'{LIB_PATH} not found: build it with `python __graft_entry__.py build` '
+            '(hipcc --offload-arch=gfx950); there is no CPU/torch fallback for the hot path')
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.argtypes = args
+        fn.restype = _RESTYPE.get(name, ctypes.c_int)
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        raise MoviigenHipError(f'{name} failed: {ERRORS.get(rc, rc)}')

@@ -1,0 +1,184 @@
+"""Thin typed wrappers: torch CUDA tensors in, C-ABI kernel launches out (on torch's current
+stream).  torch is used here for device memory and streams only — every arithmetic step is a
+libmoviigen_hip.so kernel; a failure raises, nothing falls back to torch math."""
+import ctypes
+
+import torch
+
+from . import lib
+
+BIAS_BF16, BIAS_GELU_BF16, GATE_RESID_F32, BIAS_F32 = 0, 1, 2, 3
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _st():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t, dtype, name):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise lib.MoviigenHipError(f'{name}: expected a CUDA (HIP) tensor — the hot path has no CPU fallback')
+    if t.dtype != dtype:
+        raise lib.MoviigenHipError(f'{name}: expected {dtype}, got {t.dtype}')
+    if t.dim() >= 1 and t.stride(-1) != 1:
+        raise lib.MoviigenHipError(f'{name}: innermost dimension must be contiguous')
+
+
+def ln_modulate(x, scale, shift, add_one, eps, out, round_norm_bf16=False):
+    """x [rows, dim] fp32 -> out [rows, dim] (bf16 or fp32)."""
+    _chk(x, torch.float32, 'x'); _chk(scale, torch.float32, 'scale'); _chk(shift, torch.float32, 'shift')
+    rows, dim = x.shape
+    lib.call('mg_ln_modulate', _p(x), x.stride(0), rows, dim, _p(scale), _p(shift), int(add_one), float(eps),
+             int(round_norm_bf16), _p(out), int(out.dtype == torch.float32), out.stride(0), _st())
+    return out
+
+
+def rmsnorm_rope(x, weight, eps, head_dim, out, rope_cs=None, grid=(1, 1, 1), pos0=0):
+    """x [rows, dim] bf16 (may be a strided column slice) -> out bf16."""
+    _chk(x, torch.bfloat16, 'x'); _chk(out, torch.bfloat16, 'out'); _chk(weight, torch.float32, 'weight')
+    rows, dim = x.shape
+    lib.call('mg_rmsnorm_rope_bf16', _p(x), x.stride(0), _p(out), out.stride(0), rows, dim, _p(weight), float(eps),
+             int(head_dim), _p(rope_cs), int(grid[0]), int(grid[1]), int(grid[2]), int(pos0), _st())
+    return out
+
+
+def transpose_v(v, heads, head_dim, vt):
+    """v [L, heads*head_dim] bf16 (strided ok) -> vt [heads, head_dim, Lpad] bf16 (zero padded)."""
+    _chk(v, torch.bfloat16, 'v'); _chk(vt, torch.bfloat16, 'vt')
+    lib.call('mg_transpose_v_bf16', _p(v), v.stride(0), v.shape[0], heads, head_dim, _p(vt), vt.shape[2], _st())
+    return vt
+
+
+def gemm(a, w, bias, epilogue, out, gate=None):
+    """out[M,N] (+)= a[M,K] @ w[N,K]^T (+bias ...) — see MG_EPI_* in include/moviigen_hip.h."""
+    _chk(a, torch.bfloat16, 'a'); _chk(w, torch.bfloat16, 'w'); _chk(bias, torch.float32, 'bias')
+    _chk(gate, torch.float32, 'gate')
+    want = torch.bfloat16 if epilogue in (BIAS_BF16, BIAS_GELU_BF16) else torch.float32
+    _chk(out, want, 'out')
+    M, K = a.shape
+    N = w.shape[0]
+    if w.shape[1] != K or out.shape[0] != M or out.shape[1] != N:
+        raise lib.MoviigenHipError(f'gemm shape mismatch a{tuple(a.shape)} w{tuple(w.shape)} out{tuple(out.shape)}')
+    lib.call('mg_gemm_bf16', _p(a), a.stride(0), _p(w), w.stride(0), _p(bias), M, N, K, int(epilogue), _p(out),
+             out.stride(0), _p(gate), _st())
+    return out
+
+
+def attention_hd128(q, k, vt, out, lk, heads, scale):
+    _chk(q, torch.bfloat16, 'q'); _chk(k, torch.bfloat16, 'k'); _chk(vt, torch.bfloat16, 'vt')
+    _chk(out, torch.bfloat16, 'out')
+    lib.call('mg_attn_fwd_bf16_hd128', _p(q), q.stride(0), _p(k), k.stride(0), _p(vt), vt.shape[2], _p(out),
+             out.stride(0), q.shape[0], int(lk), int(heads), float(scale), _st())
+    return out
+
+
+def attention_generic(q, k, v, out, lk, heads, head_dim, scale):
+    _chk(q, torch.bfloat16, 'q'); _chk(k, torch.bfloat16, 'k'); _chk(v, torch.bfloat16, 'v')
+    _chk(out, torch.bfloat16, 'out')
+    lib.call('mg_attn_fwd_bf16_generic', _p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(out),
+             out.stride(0), q.shape[0], int(lk), int(heads), int(head_dim), float(scale), _st())
+    return out
+
+
+def sinusoid_embed(t, dim, out):
+    code = {torch.int64: 0, torch.float32: 1, torch.float64: 2}.get(t.dtype)
+    if code is None or not t.is_cuda:
+        raise lib.MoviigenHipError('timestep must be a CUDA int64/float32/float64 tensor')
+    lib.call('mg_sinusoid_embed', _p(t), code, t.numel(), int(dim), _p(out), _st())
+    return out
+
+
+def gemv(w, bias, x, y, silu_in=False):
+    _chk(w, torch.float32, 'w'); _chk(x, torch.float32, 'x'); _chk(y, torch.float32, 'y')
+    lib.call('mg_gemv_f32', _p(w), _p(bias), _p(x), _p(y), w.shape[0], w.shape[1], int(silu_in), _st())
+    return y
+
+
+def add_rows(a, b, out, period):
+    rows, dim = a.shape
+    lib.call('mg_add_rows_f32', _p(a), _p(b), _p(out), rows, dim, int(period), _st())
+    return out
+
+
+def head_gemm(x, w, bias, out):
+    _chk(x, torch.float32, 'x'); _chk(w, torch.float32, 'w'); _chk(out, torch.float32, 'out')
+    lib.call('mg_head_gemm_f32', _p(x), x.stride(0), _p(w), _p(bias), _p(out), x.shape[0], w.shape[0], w.shape[1],
+             _st())
+    return out
+
+
+def patchify(lat, ph, pw, out):
+    _chk(lat, torch.float32, 'lat'); _chk(out, torch.bfloat16, 'out')
+    C, F, H, W = lat.shape
+    lib.call('mg_patchify_bf16', _p(lat), C, F, H, W, int(ph), int(pw), _p(out), out.stride(0), _st())
+    return out
+
+
+def unpatchify(tok, C, F, Hg, Wg, ph, pw, lat):
+    _chk(tok, torch.float32, 'tok'); _chk(lat, torch.float32, 'lat')
+    lib.call('mg_unpatchify_f32', _p(tok), tok.stride(0), C, F, Hg, Wg, int(ph), int(pw), _p(lat), _st())
+    return lat
+
+
+def lincomb(out, terms):
+    """out = sum(c_i * x_i) for up to 4 (tensor, coef) terms."""
+    terms = list(terms) + [(None, 0.0)] * (4 - len(terms))
+    args = []
+    for x, c in terms:
+        _chk(x, torch.float32, 'x')
+        args += [_p(x), float(c)]
+    lib.call('mg_lincomb4_f32', _p(out), out.numel(), *args, _st())
+    return out
+
+
+def cfg_combine(out, uncond, cond, g):
+    _chk(uncond, torch.float32, 'uncond'); _chk(cond, torch.float32, 'cond')
+    lib.call('mg_cfg_combine_f32', _p(out), _p(uncond), _p(cond), float(g), out.numel(), _st())
+    return out
+
+
+# ---- VAE (fp32, channels-last) -------------------------------------------------------------------
+def vae_conv(x, w, bias, out, kt, kh, kw, cache=None, up2=False, residual=None):
+    """x [T,H,W,Cin]; w [Cout,kt,kh,kw,Cin]; out [T,Ho,Wo,Cout]."""
+    for n, t in (('x', x), ('w', w), ('bias', bias), ('out', out), ('cache', cache), ('residual', residual)):
+        _chk(t, torch.float32, n)
+    T, H, W, Cin = x.shape
+    tc = 0 if cache is None else cache.shape[0]
+    lib.call('mg_vae_conv_f32', _p(x), _p(cache), tc, T, H, W, Cin, _p(w), _p(bias), w.shape[0], kt, kh, kw,
+             int(up2), _p(residual), _p(out), _st())
+    return out
+
+
+def vae_rmsnorm_silu(x, gamma, out, do_silu=True):
+    C = x.shape[-1]
+    lib.call('mg_vae_rmsnorm_silu_f32', _p(x), _p(gamma), _p(out), x.numel() // C, C, int(do_silu), _st())
+    return out
+
+
+def vae_attn(qkv, out, workspace):
+    frames, L, C3 = qkv.shape
+    lib.call('mg_vae_attn_f32', _p(qkv), _p(out), frames, L, C3 // 3, _p(workspace), _st())
+    return out
+
+
+def vae_latent_in(z, mean, inv_std, out):
+    C, T, H, W = z.shape
+    lib.call('mg_vae_latent_in_f32', _p(z), _p(mean), _p(inv_std), C, T, H, W, _p(out), _st())
+    return out
+
+
+def vae_video_out(x, out, t_off):
+    T, H, W, C = x.shape
+    lib.call('mg_vae_video_out_f32', _p(x), C, T, H, W, _p(out), int(t_off), out.shape[1], _st())
+    return out
+
+
+def vae_time_interleave(x, out):
+    T, H, W, C2 = x.shape
+    lib.call('mg_vae_time_interleave_f32', _p(x), T, H * W, C2 // 2, _p(out), _st())
+    return out

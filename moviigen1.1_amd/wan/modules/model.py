@@ -1,0 +1,444 @@
+"""WanModel — the MoviiGen1.1 / Wan2.1 DiT, executed by hand-written HIP kernels on MI355X.
+
+Drop-in for the reference class of the same name (reference wan/modules/model.py:361-633):
+same constructor arguments, same state_dict key names and shapes (so `from_pretrained` reads the
+reference checkpoint layout: config.json + diffusion_pytorch_model*.safetensors), same
+`forward(x, t, context, seq_len, clip_fea=None, y=None) -> List[Tensor[C,F,H,W] fp32]`.
+
+What differs is HOW a forward runs.  The reference composes ~40 torch ops per block under
+autocast; here a block is 14 kernel launches from libmoviigen_hip.so:
+
+    ln_modulate -> gemm(QKV fused, N=3*dim) -> rmsnorm_rope(q) / rmsnorm_rope(k) / transpose_v
+    -> attention -> gemm(o) with `x += y*gate` fused  -> ln_modulate(norm3 affine) -> gemm(q)
+    -> rmsnorm -> attention(512 cached text keys) -> gemm(o) with `x += y` fused
+    -> ln_modulate -> gemm(ffn.0)+GELU fused -> gemm(ffn.2) with `x += y*gate` fused
+
+The rounding points of the reference's autocast(bf16) execution are reproduced (SURVEY.md
+Appendix B): bf16 GEMM operands/results, fp32 accumulate, fp32 residual stream, fp32 norms and
+modulation, fp32 time embedding and head.  GEMM weights are stored in bf16 (what autocast feeds
+the GEMM anyway); norm weights, modulation tables, time embedding and head stay fp32.
+Per-prompt work that does not depend on the timestep (text_embedding, the 40 cross-attention
+K/V projections) is computed once per prompt and cached — identical values, 100x fewer times.
+
+There is no torch fallback: without the HIP library (or a GPU) forward() raises.
+"""
+import json
+import math
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ..backend import ops
+
+__all__ = ['WanModel']
+
+_BF16_SUFFIXES = ('.q.weight', '.k.weight', '.v.weight', '.o.weight', 'ffn.0.weight', 'ffn.2.weight',
+                  'text_embedding.0.weight', 'text_embedding.2.weight', 'patch_embedding.weight')
+
+
+class _Lin(nn.Module):
+    """parameter holder with nn.Linear's names (weight [out,in], bias [out]); no forward."""
+
+    def __init__(self, out_f, in_f, wdtype, device):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(out_f, in_f, dtype=wdtype, device=device), requires_grad=False)
+        self.bias = nn.Parameter(torch.empty(out_f, dtype=torch.float32, device=device), requires_grad=False)
+
+
+class _Vec(nn.Module):
+    def __init__(self, dim, device, bias=False):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(dim, dtype=torch.float32, device=device), requires_grad=False)
+        if bias:
+            self.bias = nn.Parameter(torch.zeros(dim, dtype=torch.float32, device=device), requires_grad=False)
+
+
+class _Attn(nn.Module):
+    def __init__(self, dim, device):
+        super().__init__()
+        for n in 'qkvo':
+            setattr(self, n, _Lin(dim, dim, torch.bfloat16, device))
+        self.norm_q = _Vec(dim, device)
+        self.norm_k = _Vec(dim, device)
+
+
+class _Block(nn.Module):
+    def __init__(self, dim, ffn_dim, device):
+        super().__init__()
+        self.self_attn = _Attn(dim, device)
+        self.norm3 = _Vec(dim, device, bias=True)
+        self.cross_attn = _Attn(dim, device)
+        self.ffn = nn.ModuleDict({'0': _Lin(ffn_dim, dim, torch.bfloat16, device),
+                                  '2': _Lin(dim, ffn_dim, torch.bfloat16, device)})
+        self.modulation = nn.Parameter(torch.empty(1, 6, dim, dtype=torch.float32, device=device),
+                                       requires_grad=False)
+
+
+class _Head(nn.Module):
+    def __init__(self, dim, out_f, device):
+        super().__init__()
+        self.head = _Lin(out_f, dim, torch.float32, device)
+        self.modulation = nn.Parameter(torch.empty(1, 2, dim, dtype=torch.float32, device=device),
+                                       requires_grad=False)
+
+
+class _PatchEmbed(nn.Module):
+    def __init__(self, dim, in_dim, patch, device):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(dim, in_dim, *patch, dtype=torch.bfloat16, device=device),
+                                   requires_grad=False)
+        self.bias = nn.Parameter(torch.empty(dim, dtype=torch.float32, device=device), requires_grad=False)
+
+
+def rope_cos_sin(head_dim, grid, theta=10000.0):
+    """(cos, sin) tables of reference model.py:28-36,473-478 for positions < (F, H, W), fp64 ->
+    fp32, laid out [F][c0] ++ [H][c1] ++ [W][c1] as mg_rmsnorm_rope_bf16 expects."""
+    c = head_dim // 2
+    c1 = c // 3
+    c0 = c - 2 * c1
+    parts = []
+    for n, cnt in zip(grid, (c0, c1, c1)):
+        inv = 1.0 / np.power(theta, np.arange(0, 2 * cnt, 2, dtype=np.float64) / (2 * cnt))
+        ang = np.outer(np.arange(n, dtype=np.float64), inv)
+        parts.append(np.stack([np.cos(ang), np.sin(ang)], axis=-1).reshape(-1, 2))
+    return torch.from_numpy(np.concatenate(parts).astype(np.float32))
+
+
+class WanModel(nn.Module):
+    ignore_for_config = ['patch_size', 'cross_attn_norm', 'qk_norm', 'text_dim', 'window_size']
+    _no_split_modules = ['WanAttentionBlock']
+
+    def __init__(self, model_type='t2v', patch_size=(1, 2, 2), text_len=512, in_dim=16, dim=2048, ffn_dim=8192,
+                 freq_dim=256, text_dim=4096, out_dim=16, num_heads=16, num_layers=32, window_size=(-1, -1),
+                 qk_norm=True, cross_attn_norm=True, eps=1e-6, device=None):
+        super().__init__()
+        if model_type != 't2v':
+            raise NotImplementedError('only the t2v path of MoviiGen1.1 is implemented (reference configs '
+                                      'register t2v-14B / t2i-14B only)')
+        if tuple(window_size) != (-1, -1) or not qk_norm or not cross_attn_norm:
+            raise NotImplementedError('window attention / qk_norm=False / cross_attn_norm=False are never used '
+                                      'by the reference configs')
+        assert dim % num_heads == 0 and (dim // num_heads) % 2 == 0
+        self.model_type, self.patch_size, self.text_len = model_type, tuple(patch_size), text_len
+        self.in_dim, self.dim, self.ffn_dim, self.freq_dim, self.text_dim = in_dim, dim, ffn_dim, freq_dim, text_dim
+        self.out_dim, self.num_heads, self.num_layers, self.eps = out_dim, num_heads, num_layers, eps
+        self.window_size, self.qk_norm, self.cross_attn_norm = window_size, qk_norm, cross_attn_norm
+        self.config = dict(model_type=model_type, text_len=text_len, in_dim=in_dim, dim=dim, ffn_dim=ffn_dim,
+                           freq_dim=freq_dim, out_dim=out_dim, num_heads=num_heads, num_layers=num_layers, eps=eps)
+        dv = device
+        self.patch_embedding = _PatchEmbed(dim, in_dim, self.patch_size, dv)
+        self.text_embedding = nn.ModuleDict({'0': _Lin(dim, text_dim, torch.bfloat16, dv),
+                                             '2': _Lin(dim, dim, torch.bfloat16, dv)})
+        self.time_embedding = nn.ModuleDict({'0': _Lin(dim, freq_dim, torch.float32, dv),
+                                             '2': _Lin(dim, dim, torch.float32, dv)})
+        self.time_projection = nn.ModuleDict({'1': _Lin(6 * dim, dim, torch.float32, dv)})
+        self.blocks = nn.ModuleList([_Block(dim, ffn_dim, dv) for _ in range(num_layers)])
+        self.head = _Head(dim, math.prod(self.patch_size) * out_dim, dv)
+        # sequence-parallel placement, installed by wan.distributed (Ulysses); 1 = single GPU
+        self.sp_size, self.sp_rank, self.sp_group = 1, 0, None
+        self._packed = None
+        self._ws = {}
+        self._rope = {}
+        self._ctx_cache = {}
+
+    # ------------------------------------------------------------------------------------------
+    # checkpoint layout (reference text2video.py:87)
+    # ------------------------------------------------------------------------------------------
+    @classmethod
+    def from_pretrained(cls, checkpoint_dir, device=None):
+        from safetensors import safe_open
+        with open(os.path.join(checkpoint_dir, 'config.json')) as f:
+            cfg = json.load(f)
+        keys = ('model_type', 'text_len', 'in_dim', 'dim', 'ffn_dim', 'freq_dim', 'out_dim', 'num_heads',
+                'num_layers', 'eps')
+        model = cls(**{k: cfg[k] for k in keys if k in cfg}, device=device)
+        idx = os.path.join(checkpoint_dir, 'diffusion_pytorch_model.safetensors.index.json')
+        if os.path.exists(idx):
+            with open(idx) as f:
+                files = sorted(set(json.load(f)['weight_map'].values()))
+        else:
+            files = sorted(f for f in os.listdir(checkpoint_dir)
+                           if f.startswith('diffusion_pytorch_model') and f.endswith('.safetensors'))
+        if not files:
+            raise FileNotFoundError(f'no diffusion_pytorch_model*.safetensors under {checkpoint_dir}')
+        own = dict(model.named_parameters())
+        seen = set()
+        for fn in files:
+            with safe_open(os.path.join(checkpoint_dir, fn), framework='pt', device='cpu') as sf:
+                for k in sf.keys():
+                    if k not in own:
+                        raise KeyError(f'unexpected checkpoint tensor {k}')
+                    own[k].data.copy_(sf.get_tensor(k).reshape(own[k].shape))
+                    seen.add(k)
+        missing = set(own) - seen
+        if missing:
+            raise KeyError(f'checkpoint is missing {sorted(missing)[:5]} ...')
+        return model
+
+    def load_state_dict(self, state_dict, strict=True, assign=False):
+        out = super().load_state_dict(state_dict, strict=strict, assign=False)
+        self._invalidate()
+        return out
+
+    def init_weights(self, seed=0, std=0.02):
+        """seeded synthetic weights: N(0, std) GEMM weights, N(0,1)/sqrt(dim)
+        modulation, unit norm weights; generated directly on the parameter's device."""
+        g = torch.Generator(device=self.patch_embedding.weight.device)
+        g.manual_seed(seed)
+        for name, p in self.named_parameters():
+            if name.endswith('modulation'):
+                p.data.copy_(torch.randn(p.shape, generator=g, device=p.device) / math.sqrt(self.dim))
+            elif 'norm' in name and name.endswith('weight'):
+                p.data.fill_(1.0)
+            elif name.endswith('bias'):
+                p.data.copy_(torch.randn(p.shape, generator=g, device=p.device) * std)
+            else:
+                p.data.copy_((torch.randn(p.shape, generator=g, device=p.device, dtype=torch.float32) * std))
+        self._invalidate()
+        return self
+
+    def _invalidate(self):
+        self._packed = None
+        self._ctx_cache = {}
+
+    def _apply(self, fn, recurse=True):
+        out = super()._apply(fn, recurse)
+        # keep the storage dtypes fixed: `.to(torch.float32)`-style casts must not widen bf16 weights
+        for name, p in self.named_parameters():
+            want = torch.bfloat16 if name.endswith(_BF16_SUFFIXES) else torch.float32
+            if p.dtype != want:
+                p.data = p.data.to(want)
+        self._invalidate()
+        self._ws, self._rope = {}, {}
+        return out
+
+    # ------------------------------------------------------------------------------------------
+    # engine-side packing: fused QKV / cross-KV weights, stacked modulation
+    # ------------------------------------------------------------------------------------------
+    def _pack(self):
+        if self._packed is not None:
+            return self._packed
+        dev = self.patch_embedding.weight.device
+        if dev.type != 'cuda':
+            raise RuntimeError('WanModel.forward needs the model on a HIP device (model.to("cuda")): the hot '
+                               'path has no CPU implementation — use oracle/ for CPU reference numbers')
+        pk = {'layers': []}
+        for b in self.blocks:
+            sa, ca = b.self_attn, b.cross_attn
+            wqkv = torch.cat([sa.q.weight, sa.k.weight, sa.v.weight], 0).contiguous()
+            # re-point the three parameters at the fused storage: no second copy of the weights
+            d = self.dim
+            sa.q.weight.data, sa.k.weight.data, sa.v.weight.data = wqkv[:d], wqkv[d:2 * d], wqkv[2 * d:]
+            wkv = torch.cat([ca.k.weight, ca.v.weight], 0).contiguous()
+            ca.k.weight.data, ca.v.weight.data = wkv[:d], wkv[d:]
+            pk['layers'].append(dict(
+                wqkv=wqkv, bqkv=torch.cat([sa.q.bias, sa.k.bias, sa.v.bias]).contiguous(),
+                wkv_c=wkv, bkv_c=torch.cat([ca.k.bias, ca.v.bias]).contiguous()))
+        pk['modulation'] = torch.cat([b.modulation.data.reshape(6, self.dim) for b in self.blocks], 0).contiguous()
+        pk['patch_w'] = self.patch_embedding.weight.data.reshape(self.dim, -1)
+        self._packed = pk
+        return pk
+
+    def _workspace(self, L, dev):
+        key = (L, str(dev))
+        ws = self._ws.get(key)
+        if ws is None:
+            d, f = self.dim, self.ffn_dim
+            bf, f32 = torch.bfloat16, torch.float32
+            hd = d // self.num_heads
+            Ltot = L * self.sp_size
+            Lpad = (Ltot + 63) // 64 * 64
+            e = lambda *s, dt=bf: torch.empty(*s, dtype=dt, device=dev)  # noqa: E731
+            ws = dict(x=e(L, d, dt=f32), h=e(L, d), qkv=e(L, 3 * d), q=e(L, d), k=e(L, d), a=e(L, d),
+                      u=e(L, f), tok=e(L, self.in_dim * math.prod(self.patch_size)),
+                      hf=e(L, d, dt=f32), y=e(L, math.prod(self.patch_size) * self.out_dim, dt=f32),
+                      sin=e(1, self.freq_dim, dt=f32), e1=e(d, dt=f32), e=e(d, dt=f32), e0=e(6, d, dt=f32),
+                      mod=e(6 * self.num_layers, d, dt=f32), hmod=e(2, d, dt=f32))
+            if hd == 128:
+                ws['vt'] = e(self.num_heads // self.sp_size, 128, Lpad)
+            if self.sp_size > 1:
+                n_loc = self.num_heads // self.sp_size
+                ws['qg'], ws['kg'], ws['vg'] = e(Ltot, n_loc * hd), e(Ltot, n_loc * hd), e(Ltot, n_loc * hd)
+                ws['ag'] = e(Ltot, n_loc * hd)
+            self._ws = {key: ws}  # one live shape at a time (activations are GBs at 14B/720p)
+        return ws
+
+    def _rope_tab(self, grid, dev):
+        key = (tuple(grid), str(dev))
+        if key not in self._rope:
+            self._rope = {key: rope_cos_sin(self.dim // self.num_heads, grid).to(dev)}
+        return self._rope[key]
+
+    # ------------------------------------------------------------------------------------------
+    # prompt-only work: text_embedding + per-layer cross-attention K/V (reference model.py:548-554,
+    # 168-170) — independent of t, so done once per prompt tensor and cached
+    # ------------------------------------------------------------------------------------------
+    def _context(self, ctx):
+        key = (ctx.data_ptr(), tuple(ctx.shape), ctx._version)
+        hit = self._ctx_cache.get(key)
+        if hit is not None:
+            return hit
+        pk = self._pack()
+        dev, d, hd = ctx.device, self.dim, self.dim // self.num_heads
+        Lc = self.text_len
+        bf = torch.bfloat16
+        pad = torch.zeros(Lc, self.text_dim, dtype=bf, device=dev)
+        pad[:ctx.shape[0]].copy_(ctx)
+        t0 = torch.empty(Lc, d, dtype=bf, device=dev)
+        emb = torch.empty(Lc, d, dtype=bf, device=dev)
+        te = self.text_embedding
+        ops.gemm(pad, te['0'].weight, te['0'].bias, ops.BIAS_GELU_BF16, t0)
+        ops.gemm(t0, te['2'].weight, te['2'].bias, ops.BIAS_BF16, emb)
+        kv = torch.empty(Lc, 2 * d, dtype=bf, device=dev)
+        layers = []
+        Lcpad = (Lc + 63) // 64 * 64
+        for b, lw in zip(self.blocks, pk['layers']):
+            ops.gemm(emb, lw['wkv_c'], lw['bkv_c'], ops.BIAS_BF16, kv)
+            kc = torch.empty(Lc, d, dtype=bf, device=dev)
+            ops.rmsnorm_rope(kv[:, :d], b.cross_attn.norm_k.weight, self.eps, hd, kc)
+            if hd == 128:
+                vc = torch.empty(self.num_heads, 128, Lcpad, dtype=bf, device=dev)
+                ops.transpose_v(kv[:, d:], self.num_heads, 128, vc)
+            else:
+                vc = kv[:, d:].clone()
+            layers.append((kc, vc))
+        if len(self._ctx_cache) >= 4:
+            self._ctx_cache.pop(next(iter(self._ctx_cache)))
+        self._ctx_cache[key] = (ctx, layers)  # keep ctx alive so data_ptr stays unique
+        return self._ctx_cache[key]
+
+    # ------------------------------------------------------------------------------------------
+    def _attention(self, q, k, v_or_vt, out, lk, heads):
+        hd = self.dim // self.num_heads
+        scale = 1.0 / math.sqrt(hd)
+        if hd == 128:
+            ops.attention_hd128(q, k, v_or_vt, out, lk, heads, scale)
+        else:
+            ops.attention_generic(q, k, v_or_vt, out, lk, heads, hd, scale)
+
+    def _self_attention(self, ws, blk, grid, rope, L, pos0):
+        """model.py:127-156 (and the Ulysses variant xdit_context_parallel.py:155-198)."""
+        d, hd, N = self.dim, self.dim // self.num_heads, self.num_heads
+        qkv = ws['qkv']
+        sa = blk.self_attn
+        ops.rmsnorm_rope(qkv[:, :d], sa.norm_q.weight, self.eps, hd, ws['q'], rope, grid, pos0)
+        ops.rmsnorm_rope(qkv[:, d:2 * d], sa.norm_k.weight, self.eps, hd, ws['k'], rope, grid, pos0)
+        if self.sp_size == 1:
+            if hd == 128:
+                ops.transpose_v(qkv[:, 2 * d:], N, 128, ws['vt'])
+                self._attention(ws['q'], ws['k'], ws['vt'], ws['a'], self._kv_valid, N)
+            else:
+                self._attention(ws['q'], ws['k'], qkv[:, 2 * d:], ws['a'], self._kv_valid, N)
+            return
+        from ..distributed import ulysses
+        n_loc = N // self.sp_size
+        ulysses.seq_to_head(ws['q'], ws['qg'], self.sp_group, self.sp_size, N, hd)
+        ulysses.seq_to_head(ws['k'], ws['kg'], self.sp_group, self.sp_size, N, hd)
+        ulysses.seq_to_head(qkv[:, 2 * d:], ws['vg'], self.sp_group, self.sp_size, N, hd)
+        Ltot = L * self.sp_size
+        if hd == 128:
+            ops.transpose_v(ws['vg'], n_loc, 128, ws['vt'])
+            self._attention(ws['qg'], ws['kg'], ws['vt'], ws['ag'], Ltot, n_loc)
+        else:
+            self._attention(ws['qg'], ws['kg'], ws['vg'], ws['ag'], Ltot, n_loc)
+        ulysses.head_to_seq(ws['ag'], ws['a'], self.sp_group, self.sp_size, N, hd)
+
+    @torch.no_grad()
+    def _forward_one(self, lat, t, ctx, seq_len):
+        pk = self._pack()
+        dev = lat.device
+        lat = lat.to(torch.float32).contiguous()
+        C, F, H, W = lat.shape
+        pt, ph, pw = self.patch_size
+        assert pt == 1, 'temporal patch size 1 (reference config)'
+        grid = (F, H // ph, W // pw)
+        Lfull = grid[0] * grid[1] * grid[2]
+        assert Lfull <= seq_len, 'seq_lens.max() <= seq_len (reference model.py:534)'
+        P = self.sp_size
+        if P > 1:
+            # reference SP path does not mask padded keys (xdit_context_parallel.py:178-193): it is
+            # only correct without padding, which is what every supported size gives
+            assert seq_len == Lfull and Lfull % P == 0 and self.num_heads % P == 0, \
+                'sequence parallel needs L % sp == 0, heads % sp == 0 and no padding'
+        L = Lfull // P
+        pos0 = self.sp_rank * L
+        self._kv_valid = Lfull
+        d, eps = self.dim, self.eps
+        ws = self._workspace(L, dev)
+        x = ws['x']
+
+        # patch embedding (model.py:529-531): bf16 result, residual stream kept in fp32 storage
+        if P == 1:
+            ops.patchify(lat, ph, pw, ws['tok'])
+        else:
+            full = torch.empty(Lfull, ws['tok'].shape[1], dtype=torch.bfloat16, device=dev)
+            ops.patchify(lat, ph, pw, full)
+            ws['tok'].copy_(full[pos0:pos0 + L])  # torch.chunk(x, P, dim=1)[rank]
+        ops.gemm(ws['tok'], pk['patch_w'], self.patch_embedding.bias, ops.BIAS_F32, x)
+
+        # time embedding (model.py:541-545), fp32
+        tt = t.reshape(1).to(dev)
+        if tt.dtype not in (torch.int64, torch.float32, torch.float64):
+            tt = tt.to(torch.float32)
+        ops.sinusoid_embed(tt, self.freq_dim, ws['sin'])
+        te, tp = self.time_embedding, self.time_projection['1']
+        ops.gemv(te['0'].weight, te['0'].bias, ws['sin'], ws['e1'])
+        ops.gemv(te['2'].weight, te['2'].bias, ws['e1'], ws['e'], silu_in=True)
+        ops.gemv(tp.weight, tp.bias, ws['e'], ws['e0'], silu_in=True)
+        ops.add_rows(pk['modulation'], ws['e0'], ws['mod'], 6)                       # model.py:292-295
+        ops.add_rows(self.head.modulation.data.reshape(2, d), ws['e'].reshape(1, d), ws['hmod'], 1)
+
+        _, ctx_layers = self._context(ctx)
+        rope = self._rope_tab(grid, dev)
+        mod = ws['mod']
+
+        for i, (blk, lw) in enumerate(zip(self.blocks, pk['layers'])):
+            m = mod[6 * i:6 * i + 6]
+            # self attention
+            ops.ln_modulate(x, m[1], m[0], True, eps, ws['h'], round_norm_bf16=(i == 0))
+            ops.gemm(ws['h'], lw['wqkv'], lw['bqkv'], ops.BIAS_BF16, ws['qkv'])
+            self._self_attention(ws, blk, grid, rope, L, pos0)
+            ops.gemm(ws['a'], blk.self_attn.o.weight, blk.self_attn.o.bias, ops.GATE_RESID_F32, x, gate=m[2])
+            # cross attention (text keys/values cached per prompt)
+            ca = blk.cross_attn
+            kc, vc = ctx_layers[i]
+            ops.ln_modulate(x, blk.norm3.weight, blk.norm3.bias, False, eps, ws['h'])
+            ops.gemm(ws['h'], ca.q.weight, ca.q.bias, ops.BIAS_BF16, ws['q'])
+            ops.rmsnorm_rope(ws['q'], ca.norm_q.weight, eps, d // self.num_heads, ws['k'])
+            self._attention(ws['k'], kc, vc, ws['a'], self.text_len, self.num_heads)
+            ops.gemm(ws['a'], ca.o.weight, ca.o.bias, ops.GATE_RESID_F32, x, gate=None)
+            # ffn
+            ops.ln_modulate(x, m[4], m[3], True, eps, ws['h'])
+            ops.gemm(ws['h'], blk.ffn['0'].weight, blk.ffn['0'].bias, ops.BIAS_GELU_BF16, ws['u'])
+            ops.gemm(ws['u'], blk.ffn['2'].weight, blk.ffn['2'].bias, ops.GATE_RESID_F32, x, gate=m[5])
+
+        # head (model.py:333-343): fp32 end to end
+        ops.ln_modulate(x, ws['hmod'][1], ws['hmod'][0], True, eps, ws['hf'])
+        ops.head_gemm(ws['hf'], self.head.head.weight, self.head.head.bias, ws['y'])
+        y = ws['y']
+        if P > 1:
+            from ..distributed import ulysses
+            y = ulysses.all_gather_seq(ws['y'], self.sp_group, P)                   # get_sp_group().all_gather
+        out = torch.empty(self.out_dim, F, H, W, dtype=torch.float32, device=dev)
+        ops.unpatchify(y, self.out_dim, grid[0], grid[1], grid[2], ph, pw, out)
+        return out
+
+    def forward(self, x, t, context, seq_len, clip_fea=None, y=None):
+        if clip_fea is not None or y is not None:
+            raise NotImplementedError('image conditioning (i2v) is not part of MoviiGen1.1 T2V')
+        t = t.reshape(-1)
+        return [self._forward_one(u, t[i if t.numel() > 1 else 0], c, seq_len)
+                for i, (u, c) in enumerate(zip(x, context))]
+
+    def unpatchify(self, x, grid_sizes):
+        outs = []
+        for u, v in zip(x, grid_sizes.tolist()):
+            f, h, w = v
+            out = torch.empty(self.out_dim, f * self.patch_size[0], h * self.patch_size[1], w * self.patch_size[2],
+                              dtype=torch.float32, device=u.device)
+            ops.unpatchify(u.to(torch.float32).contiguous(), self.out_dim, f, h, w, self.patch_size[1],
+                           self.patch_size[2], out)
+            outs.append(out)
+        return outs

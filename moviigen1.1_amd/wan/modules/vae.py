@@ -1,0 +1,184 @@
+"""WanVAE decode on MI355X — drop-in for the decode side of reference wan/modules/vae.py.
+
+Public surface kept: `WanVAE(z_dim=16, vae_pth=..., dtype=torch.float, device=...)`,
+`.model.z_dim`, `.decode(list[Tensor[16,T,h,w]]) -> list[Tensor[3,4T-3,8h,8w]]` fp32 in [-1,1]
+(reference vae.py:619-663), reading the reference checkpoint `Wan2.1_VAE.pth` (a plain
+state_dict; encoder tensors are ignored: VAE *encode* is training-side preprocessing, out of the
+denoising hot path).
+
+Execution: activations are channels-last [T][H][W][C] fp32 on the device; every convolution
+(3x3x3 causal, 3x1x1 time_conv, 3x3 after nearest-2x, 1x1) is ONE implicit-GEMM launch on the
+exact-f32 MFMA (mg_vae_conv_f32) with the causal cache, the zero padding, the 2x upsample, the
+bias and the residual add folded in; RMS_norm+SiLU and the per-frame d=384 attention are HIP
+kernels as well.  The chunked decode with its 2-frame feature cache follows the reference
+protocol (vae.py:101-141,202-220,423-472,544-568) slot for slot.
+"""
+import logging
+
+import torch
+
+from ..backend import ops
+
+__all__ = ['WanVAE']
+
+CACHE_T = 2
+
+_MEAN = [-0.7571, -0.7089, -0.9113, 0.1075, -0.1745, 0.9653, -0.1517, 1.5508,
+         0.4134, -0.0715, 0.5517, -0.3632, -0.1922, -0.9497, 0.2503, -0.2921]
+_STD = [2.8184, 1.4541, 2.3275, 2.6558, 1.2196, 1.7708, 2.6052, 2.0743,
+        3.2687, 2.1526, 2.8652, 1.5579, 1.6382, 1.1253, 2.8251, 1.9160]
+
+
+class WanVAE_:
+    """decoder-side container: parameters keyed by the reference state_dict names, repacked for
+    the channels-last kernels ([Cout,Cin,kt,kh,kw] -> [Cout,kt,kh,kw,Cin])."""
+
+    def __init__(self, state_dict, z_dim=16, device='cuda'):
+        self.z_dim = z_dim
+        self.device = torch.device(device)
+        self.P = {}
+        for k, v in state_dict.items():
+            if not (k.startswith('decoder.') or k.startswith('conv2.')):
+                continue
+            v = v.to(torch.float32)
+            if k.endswith('weight') and v.dim() == 5:
+                v = v.permute(0, 2, 3, 4, 1)
+            elif k.endswith('weight') and v.dim() == 4:      # Conv2d -> kt = 1
+                v = v.permute(0, 2, 3, 1).unsqueeze(1)
+            elif k.endswith('gamma'):
+                v = v.reshape(-1)
+            self.P[k] = v.contiguous().to(self.device)
+        n_up = 1 + max(int(k.split('.')[2]) for k in self.P if k.startswith('decoder.upsamples.'))
+        self.layout = []
+        for i in range(n_up):
+            pre = f'decoder.upsamples.{i}.'
+            self.layout.append(('up' if (pre + 'resample.1.weight') in self.P else 'res', pre))
+        self.n_slots = sum(1 for k, v in self.P.items()
+                           if k.startswith('decoder.') and k.endswith('weight') and v.dim() == 5 and
+                           'resample' not in k and 'to_qkv' not in k and 'proj' not in k)
+        self.mean = torch.tensor(_MEAN[:z_dim], dtype=torch.float32, device=self.device)
+        self.inv_std = (1.0 / torch.tensor(_STD[:z_dim], dtype=torch.float32)).to(self.device)
+
+    # ---- building blocks -----------------------------------------------------------------------
+    def _new(self, *shape):
+        return torch.empty(*shape, dtype=torch.float32, device=self.device)
+
+    def _conv(self, name, x, cache=None, up2=False, residual=None):
+        w = self.P[name + '.weight']
+        kt, kh, kw = w.shape[1:4]
+        T, H, W, _ = x.shape
+        out = self._new(T, 2 * H if up2 else H, 2 * W if up2 else W, w.shape[0])
+        return ops.vae_conv(x, w, self.P[name + '.bias'], out, kt, kh, kw, cache=cache, up2=up2, residual=residual)
+
+    def _cached_conv(self, name, x, cache, idx, residual=None):
+        """the feat_cache protocol of every 3x3x3 conv (reference vae.py:205-217)."""
+        i = idx[0]
+        prev = cache[i]
+        if x.shape[0] >= CACHE_T:
+            cx = x[-CACHE_T:].clone()
+        elif prev is not None:
+            cx = torch.cat([prev[-1:], x[-1:]], dim=0)
+        else:
+            cx = x[-1:].clone()
+        out = self._conv(name, x, cache=prev, residual=residual)
+        cache[i] = cx
+        idx[0] += 1
+        return out
+
+    def _norm_silu(self, x, gamma, silu=True):
+        return ops.vae_rmsnorm_silu(x, self.P[gamma], self._new(*x.shape), silu)
+
+    def _res(self, pre, x, cache, idx):
+        h = x
+        if (pre + 'shortcut.weight') in self.P:
+            h = self._conv(pre + 'shortcut', x)
+        y = self._norm_silu(x, pre + 'residual.0.gamma')
+        y = self._cached_conv(pre + 'residual.2', y, cache, idx)
+        y = self._norm_silu(y, pre + 'residual.3.gamma')
+        return self._cached_conv(pre + 'residual.6', y, cache, idx, residual=h)
+
+    def _attn(self, pre, x):
+        T, H, W, C = x.shape
+        L = H * W
+        y = self._norm_silu(x, pre + 'norm.gamma', silu=False)
+        qkv = self._conv(pre + 'to_qkv', y)
+        a = self._new(T, H, W, C)
+        ws = self._new(L * L + C * L)
+        ops.vae_attn(qkv.view(T, L, 3 * C), a.view(T, L, C), ws)
+        return self._conv(pre + 'proj', a, residual=x)
+
+    def _up(self, pre, x, cache, idx):
+        if (pre + 'time_conv.weight') in self.P:       # upsample3d (reference vae.py:103-137)
+            i = idx[0]
+            if cache[i] is None:
+                cache[i] = 'Rep'
+                idx[0] += 1
+            else:
+                rep = isinstance(cache[i], str)
+                if x.shape[0] >= CACHE_T:
+                    cx = x[-CACHE_T:].clone()
+                elif rep:
+                    cx = torch.cat([torch.zeros_like(x[-1:]), x[-1:]], dim=0)
+                else:
+                    cx = torch.cat([cache[i][-1:], x[-1:]], dim=0)
+                y = self._conv(pre + 'time_conv', x, cache=None if rep else cache[i])
+                cache[i] = cx
+                idx[0] += 1
+                T, H, W, C2 = y.shape
+                x = ops.vae_time_interleave(y, self._new(2 * T, H, W, C2 // 2))
+        return self._conv(pre + 'resample.1', x, up2=True)
+
+    def _decoder_chunk(self, x, cache):
+        idx = [0]
+        x = self._cached_conv('decoder.conv1', x, cache, idx)
+        x = self._res('decoder.middle.0.', x, cache, idx)
+        x = self._attn('decoder.middle.1.', x)
+        x = self._res('decoder.middle.2.', x, cache, idx)
+        for kind, pre in self.layout:
+            x = self._res(pre, x, cache, idx) if kind == 'res' else self._up(pre, x, cache, idx)
+        x = self._norm_silu(x, 'decoder.head.0.gamma')
+        return self._cached_conv('decoder.head.2', x, cache, idx)
+
+    @torch.no_grad()
+    def decode(self, z, chunks=None):
+        """z [16,T,h,w] -> [3, 1+4(T-1), 8h, 8w] fp32 clamped to [-1,1]."""
+        z = z.to(self.device, torch.float32).contiguous()
+        C, T, H, W = z.shape
+        x = ops.vae_latent_in(z, self.mean, self.inv_std, self._new(T, H, W, C))
+        x = self._conv('conv2', x)
+        if chunks is None:
+            chunks = [1] * T                     # the reference's chunking (vae.py:555-566)
+        assert sum(chunks) == T and chunks[0] == 1
+        cache = [None] * (self.n_slots + 8)
+        video = self._new(3, 1 + 4 * (T - 1), 8 * H, 8 * W)
+        t0, f0 = 0, 0
+        for n in chunks:
+            y = self._decoder_chunk(x[t0:t0 + n], cache)
+            ops.vae_video_out(y, video, f0)
+            t0 += n
+            f0 += y.shape[0]
+        assert f0 == video.shape[1]
+        return video
+
+
+class WanVAE:
+
+    def __init__(self, z_dim=16, vae_pth='cache/vae_step_411000.pth', dtype=torch.float, device='cuda',
+                 state_dict=None):
+        if dtype not in (torch.float, torch.float32):
+            raise NotImplementedError('the reference decodes in fp32 (vae.py:623,658); so does this engine')
+        self.dtype = dtype
+        self.device = device
+        if state_dict is None:
+            logging.info(f'loading {vae_pth}')
+            state_dict = torch.load(vae_pth, map_location='cpu', weights_only=True)
+        self.model = WanVAE_(state_dict, z_dim=z_dim, device=device)
+        self.mean, self.std = torch.tensor(_MEAN[:z_dim]), torch.tensor(_STD[:z_dim])
+        self.scale = [self.mean, 1.0 / self.std]
+
+    def encode(self, videos):
+        raise NotImplementedError('VAE encode is training-side preprocessing (reference '
+                                  'scripts/data_preprocess), outside the denoising hot path')
+
+    def decode(self, zs):
+        return [self.model.decode(u) for u in zs]

@@ -1,0 +1,136 @@
+"""WanT2V — the drop-in pipeline surface (reference wan/text2video.py:28-271).
+
+Same constructor and `generate()` signature, defaults and return contract
+(Tensor[3, frame_num, H, W] fp32 in [-1,1] on rank 0, None elsewhere).  What runs underneath is
+the MI355X engine: WanModel (HIP kernels), the fused-update schedulers, WanVAE (HIP kernels),
+Ulysses over RCCL when `use_usp`, block-sharded weights when `dit_fsdp`.
+
+The umT5-XXL text encoder is the step BEFORE the hot path: its output
+`[<=512, 4096]` is an input of this pipeline.  `input_prompt` / `n_prompt` may therefore also be
+pre-computed embedding tensors; strings need a `text_encoder` callable (prompt list, device) ->
+list of tensors, exactly the reference's T5EncoderModel.__call__ contract.
+"""
+import gc
+import logging
+import math
+import os
+import random
+import sys
+
+import torch
+import torch.distributed as dist
+
+from .backend import ops
+from .modules.model import WanModel
+from .modules.vae import WanVAE
+from .utils.fm_solvers import FlowDPMSolverMultistepScheduler, get_sampling_sigmas, retrieve_timesteps
+from .utils.fm_solvers_unipc import FlowUniPCMultistepScheduler
+
+
+class WanT2V:
+
+    def __init__(self, config, checkpoint_dir, device_id=0, rank=0, t5_fsdp=False, dit_fsdp=False, use_usp=False,
+                 t5_cpu=False, text_encoder=None, model=None, vae=None):
+        self.device = torch.device(f'cuda:{device_id}')
+        self.config = config
+        self.rank = rank
+        self.t5_cpu = t5_cpu
+        self.num_train_timesteps = config.num_train_timesteps
+        self.param_dtype = config.param_dtype
+        self.text_encoder = text_encoder
+        self.vae_stride = config.vae_stride
+        self.patch_size = config.patch_size
+        self.vae = vae if vae is not None else WanVAE(
+            vae_pth=os.path.join(checkpoint_dir, config.vae_checkpoint), device=self.device)
+        if model is None:
+            logging.info(f'Creating WanModel from {checkpoint_dir}')
+            model = WanModel.from_pretrained(checkpoint_dir)
+        self.model = model
+        self.model.eval().requires_grad_(False)
+        if dist.is_initialized():
+            dist.barrier()
+        self.model.to(self.device)
+        if use_usp:
+            from .distributed.xdit_context_parallel import enable_sequence_parallel
+            enable_sequence_parallel(self.model)
+            self.sp_size = self.model.sp_size
+        else:
+            self.sp_size = 1
+        if dit_fsdp:
+            from .distributed.fsdp import shard_model
+            self.model = shard_model(self.model, device_id=device_id)
+        self.sample_neg_prompt = config.sample_neg_prompt
+
+    def _encode(self, prompt):
+        if torch.is_tensor(prompt):
+            return [prompt.to(self.device)]
+        if isinstance(prompt, (list, tuple)) and prompt and torch.is_tensor(prompt[0]):
+            return [p.to(self.device) for p in prompt]
+        if self.text_encoder is None:
+            raise NotImplementedError(
+                'no text encoder attached: pass pre-computed umT5 embeddings ([len<=512, 4096] tensors) as '
+                '`input_prompt`/`n_prompt`, or construct WanT2V(text_encoder=callable)')
+        dev = torch.device('cpu') if self.t5_cpu else self.device
+        return [t.to(self.device) for t in self.text_encoder([prompt], dev)]
+
+    def generate(self, input_prompt, size=(1280, 720), frame_num=81, shift=5.0, sample_solver='unipc',
+                 sampling_steps=50, guide_scale=5.0, n_prompt="", seed=-1, offload_model=True,
+                 noise=None, callback=None):
+        F = frame_num
+        target_shape = (self.vae.model.z_dim, (F - 1) // self.vae_stride[0] + 1, size[1] // self.vae_stride[1],
+                        size[0] // self.vae_stride[2])
+        seq_len = math.ceil((target_shape[2] * target_shape[3]) / (self.patch_size[1] * self.patch_size[2]) *
+                            target_shape[1] / self.sp_size) * self.sp_size
+        if isinstance(n_prompt, str) and n_prompt == "":
+            n_prompt = self.sample_neg_prompt
+        seed = seed if seed >= 0 else random.randint(0, sys.maxsize)
+        seed_g = torch.Generator(device=self.device)
+        seed_g.manual_seed(seed)
+        context = self._encode(input_prompt)
+        context_null = self._encode(n_prompt)
+        if noise is None:
+            noise = torch.randn(*target_shape, dtype=torch.float32, device=self.device, generator=seed_g)
+        else:
+            noise = noise.to(self.device, torch.float32)
+            assert tuple(noise.shape) == tuple(target_shape)
+
+        with torch.no_grad():
+            if sample_solver == 'unipc':
+                sample_scheduler = FlowUniPCMultistepScheduler(
+                    num_train_timesteps=self.num_train_timesteps, shift=1, use_dynamic_shifting=False)
+                sample_scheduler.set_timesteps(sampling_steps, device=self.device, shift=shift)
+                timesteps = sample_scheduler.timesteps
+            elif sample_solver == 'dpm++':
+                sample_scheduler = FlowDPMSolverMultistepScheduler(
+                    num_train_timesteps=self.num_train_timesteps, shift=1, use_dynamic_shifting=False)
+                sampling_sigmas = get_sampling_sigmas(sampling_steps, shift)
+                timesteps, _ = retrieve_timesteps(sample_scheduler, device=self.device, sigmas=sampling_sigmas)
+            else:
+                raise NotImplementedError("Unsupported solver.")
+
+            latent = noise
+            timesteps_host = timesteps.tolist()          # ONE sync for the whole loop
+            self.model.to(self.device)
+            noise_pred = torch.empty_like(latent)
+            for i, t_host in enumerate(timesteps_host):
+                t = timesteps[i:i + 1]
+                cond = self.model([latent], t=t, context=context, seq_len=seq_len)[0]
+                uncond = self.model([latent], t=t, context=context_null, seq_len=seq_len)[0]
+                ops.cfg_combine(noise_pred, uncond, cond, guide_scale)
+                latent = sample_scheduler.step(noise_pred.unsqueeze(0), t_host, latent.unsqueeze(0),
+                                               return_dict=False, generator=seed_g)[0].squeeze(0)
+                if callback is not None:
+                    callback(i, latent)
+            x0 = [latent]
+            if offload_model:
+                self.model.cpu()
+                torch.cuda.empty_cache()
+            videos = self.vae.decode(x0) if self.rank == 0 else None
+
+        del noise, latent, sample_scheduler
+        if offload_model:
+            gc.collect()
+            torch.cuda.synchronize()
+        if dist.is_initialized():
+            dist.barrier()
+        return videos[0] if self.rank == 0 else None

@@ -1,0 +1,403 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C-ABI, against
+  (1) the oracle (oracle/*.py) on the same seeded inputs,
+  (2) the committed golden vectors produced by the imported reference (tests/golden/*.npz),
+  (3) size-independent properties at BASELINE.json's full sizes (L = 75 600, d = 5120).
+
+Stated tolerances (floating-point path):
+  fp32 kernels (VAE, head, schedulers, layout)            : <= 1e-4 of the tensor scale
+  bf16-output kernels vs the bf16-emulating oracle          : <= 2 bf16 ulp-ish, 2e-2 of the scale
+  whole DiT forward in bf16 mode vs fp32 reference output   : rel-L2 <= 2e-2 (north-star tolerance)
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import weights as W
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def scale_err(a, b):
+    a, b = a.detach().double().cpu(), T(b).double() if not torch.is_tensor(b) else b.detach().double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
+
+
+def rel_l2(a, b):
+    a, b = a.detach().double().cpu(), T(b).double() if not torch.is_tensor(b) else b.detach().double().cpu()
+    return ((a - b).norm() / b.norm()).item()
+
+
+@pytest.fixture(scope='module')
+def dev():
+    return torch.device('cuda:0')
+
+
+def test_native_library_is_loaded():
+    """the test process must really be running the in-tree HIP library."""
+    from wan.backend import lib
+    lib.load()
+    maps = open('/proc/self/maps').read()
+    assert 'libmoviigen_hip.so' in maps
+
+
+# ------------------------------------------------------------------------------------------------
+# kernels through the C-ABI vs oracle functions
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('rows,dim', [(37, 5120), (5, 128), (300, 256), (0, 128)])
+def test_ln_modulate(dev, rows, dim):
+    from oracle import dit
+    from wan.backend import ops
+    x = W.randn((rows, dim), 1) * 3
+    sc, sh = W.randn((dim,), 2), W.randn((dim,), 3)
+    ref = dit.layernorm(x, 1e-6) * (1 + sc) + sh
+    out = torch.empty(rows, dim, dtype=torch.float32, device=dev)
+    ops.ln_modulate(x.to(dev), sc.to(dev), sh.to(dev), True, 1e-6, out)
+    outb = torch.empty(rows, dim, dtype=torch.bfloat16, device=dev)
+    ops.ln_modulate(x.to(dev), sc.to(dev), sh.to(dev), True, 1e-6, outb)
+    if rows:
+        assert scale_err(out, ref) < 1e-5
+        assert scale_err(outb.float(), ref.bfloat16().float()) < 1e-2
+    # norm3: affine weight/bias, no (1+)
+    ref3 = dit.layernorm(x, 1e-6, sc, sh)
+    ops.ln_modulate(x.to(dev), sc.to(dev), sh.to(dev), False, 1e-6, out)
+    if rows:
+        assert scale_err(out, ref3) < 1e-5
+
+
+@pytest.mark.parametrize('dim,hd,grid,rows,pos0', [(5120, 128, (2, 5, 5), 60, 0), (5120, 128, (2, 5, 5), 25, 25),
+                                                   (128, 32, (1, 4, 4), 16, 0), (256, 128, (2, 4, 6), 48, 0)])
+def test_rmsnorm_rope(dev, dim, hd, grid, rows, pos0):
+    from oracle import dit
+    from wan.backend import ops
+    from wan.modules.model import rope_cos_sin
+    x = (W.randn((rows, dim), 4) * 2).bfloat16()
+    w = 1 + 0.1 * W.randn((dim,), 5)
+    n = dim // hd
+    ref = dit.rope(dit.rmsnorm(x.float(), w, 1e-6, True).view(rows, n, hd), grid, dit.rope_table(hd), pos0)
+    ref = ref.reshape(rows, dim).bfloat16().float()
+    out = torch.empty(rows, dim, dtype=torch.bfloat16, device=dev)
+    ops.rmsnorm_rope(x.to(dev), w.to(dev), 1e-6, hd, out, rope_cos_sin(hd, grid).to(dev), grid, pos0)
+    assert scale_err(out.float(), ref) < 1e-2
+    # strided input (column slice of a fused qkv buffer) and no-rope variant (cross attention)
+    wide = torch.zeros(rows, 3 * dim, dtype=torch.bfloat16, device=dev)
+    wide[:, dim:2 * dim] = x.to(dev)
+    ops.rmsnorm_rope(wide[:, dim:2 * dim], w.to(dev), 1e-6, hd, out)
+    ref2 = dit.rmsnorm(x.float(), w, 1e-6, True).bfloat16().float()
+    assert scale_err(out.float(), ref2) < 1e-2
+
+
+@pytest.mark.parametrize('M,N,K', [(300, 256, 128), (129, 200, 192), (1, 64, 64), (1000, 1280, 1024), (77, 5120, 5120)])
+@pytest.mark.parametrize('epi', [0, 1, 2, 3])
+def test_gemm_epilogues(dev, M, N, K, epi):
+    from oracle import dit
+    from wan.backend import ops
+    a = (W.randn((M, K), 6)).bfloat16()
+    w = (W.randn((N, K), 7) * 0.05).bfloat16()
+    b, g = W.randn((N,), 8), W.randn((N,), 9)
+    y = dit.linear(a.float(), w.float(), b, True)  # bf16-rounded Linear output
+    ad, wd, bd, gd = a.to(dev), w.to(dev), b.to(dev), g.to(dev)
+    if epi == 0:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        ops.gemm(ad, wd, bd, epi, out)
+        ref = y
+    elif epi == 1:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        ops.gemm(ad, wd, bd, epi, out)
+        ref = torch.nn.functional.gelu(y, approximate='tanh').bfloat16().float()
+    elif epi == 2:
+        r0 = W.randn((M, N), 10)
+        out = r0.to(dev).clone()
+        ops.gemm(ad, wd, bd, epi, out, gate=gd)
+        ref = r0 + y * g
+    else:
+        out = torch.empty(M, N, dtype=torch.float32, device=dev)
+        ops.gemm(ad, wd, bd, epi, out)
+        ref = y
+    # one bf16 ulp of slack for accumulation-order differences at a rounding boundary
+    assert scale_err(out.float(), ref) < 1.2e-2
+
+
+def test_gemm_rejects_bad_shapes(dev):
+    from wan.backend import lib, ops
+    a = torch.zeros(8, 96, dtype=torch.bfloat16, device=dev)      # K % 64 != 0
+    w = torch.zeros(8, 96, dtype=torch.bfloat16, device=dev)
+    with pytest.raises(lib.MoviigenHipError):
+        ops.gemm(a, w, None, 0, torch.zeros(8, 8, dtype=torch.bfloat16, device=dev))
+    with pytest.raises(lib.MoviigenHipError):
+        ops.gemm(a.cpu(), w, None, 0, torch.zeros(8, 8, dtype=torch.bfloat16, device=dev))
+
+
+@pytest.mark.parametrize('Lq,Lk,heads,hd', [(300, 300, 2, 128), (700, 512, 3, 128), (64, 64, 1, 128), (1000, 77, 1, 128),
+                                             (16, 16, 4, 32), (50, 37, 2, 64), (1, 1, 1, 128)])
+def test_attention_vs_oracle(dev, Lq, Lk, heads, hd):
+    from oracle import dit
+    from wan.modules.attention import flash_attention
+    q = (W.randn((1, Lq, heads, hd), 11) * 1.5).bfloat16()
+    k = (W.randn((1, Lk, heads, hd), 12) * 1.5).bfloat16()
+    v = W.randn((1, Lk, heads, hd), 13).bfloat16()
+    ref = dit.attention(q[0].float(), k[0].float(), v[0].float(), Lk, True)
+    out = flash_attention(q.to(dev), k.to(dev), v.to(dev))
+    assert out.dtype == torch.bfloat16 and out.shape == q.shape
+    assert scale_err(out[0].float(), ref) < 2e-2
+    # k_lens masking (reference attention.py:71-79) and fp32 in -> fp32 out dtype contract
+    if Lk > 8:
+        kl = Lk - 5
+        ref2 = dit.attention(q[0].float(), k[0].float(), v[0].float(), kl, True)
+        out2 = flash_attention(q.float().to(dev), k.float().to(dev), v.float().to(dev), k_lens=torch.tensor([kl]))
+        assert out2.dtype == torch.float32
+        assert scale_err(out2[0], ref2) < 2e-2
+
+
+def test_attention_rescale_branch(dev):
+    """force the online-softmax rescale (a key tile whose scores dwarf the earlier ones) and check
+    lazy (defer-max) == eager rescaling (cdna guide §5.4 rule 26)."""
+    from oracle import dit
+    from wan.backend import lib
+    from wan.modules.attention import flash_attention
+    Lq, Lk = 256, 640
+    q = (W.randn((1, Lq, 1, 128), 14)).bfloat16()
+    k = (W.randn((1, Lk, 1, 128), 15) * 0.2).bfloat16()
+    v = W.randn((1, Lk, 1, 128), 16).bfloat16()
+    k[0, 300] = (q[0, 7] * 4).clone()          # tile 4 spikes for query 7
+    k[0, 500] = (q[0, 100] * 6).clone()        # tile 7 spikes for query 100
+    ref = dit.attention(q[0].float(), k[0].float(), v[0].float(), Lk, True)
+    outs = []
+    for lazy in (0, 1):
+        lib.load().mg_attn_set_lazy_rescale(lazy)
+        outs.append(flash_attention(q.to(dev), k.to(dev), v.to(dev))[0].float())
+        assert scale_err(outs[-1], ref) < 2e-2, lazy
+    lib.load().mg_attn_set_lazy_rescale(1)
+    assert scale_err(outs[0], outs[1]) < 2e-2
+
+
+def test_small_fp32_kernels(dev):
+    from oracle import dit
+    from wan.backend import ops
+    # sinusoid (model.py:15-25)
+    t = torch.tensor([999, 500, 3])
+    out = torch.empty(3, 256, dtype=torch.float32, device=dev)
+    ops.sinusoid_embed(t.to(dev), 256, out)
+    assert scale_err(out, dit.sinusoid(256, t).float()) < 1e-6
+    # unpatchify vs golden-checked oracle
+    tok = W.randn((24, 64), 13)
+    lat = torch.empty(16, 2, 6, 8, dtype=torch.float32, device=dev)
+    ops.unpatchify(tok.to(dev), 16, 2, 3, 4, 2, 2, lat)
+    assert torch.equal(lat.cpu(), dit.unpatchify(tok, (2, 3, 4), (1, 2, 2), 16))
+    # cfg combine, exact op order of text2video.py:245-246
+    u, c = W.randn((1000,), 20), W.randn((1000,), 21)
+    o = torch.empty(1000, dtype=torch.float32, device=dev)
+    ops.cfg_combine(o, u.to(dev), c.to(dev), 5.0)
+    assert scale_err(o, u + 5.0 * (c - u)) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------
+# whole DiT forward: HIP engine vs golden (reference outputs) and vs the oracle
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('tag,cfg', [('hd128', W.SMALL_DIT_HD128), ('tiny', W.TINY_DIT), ('tiny_pad', W.TINY_DIT)])
+def test_dit_forward_vs_reference(dev, golden, tag, cfg):
+    import wan
+    from oracle import dit
+    g = golden(f'g3_dit_{tag}')
+    P = W.make_dit_params(cfg, 0)
+    m = wan.modules.WanModel(**cfg)
+    m.load_state_dict(P)
+    m.to(dev)
+    j = 0
+    while f'ctx{j}' in g:
+        lat, t, ctx = T(g['lat']), T(g[f't{j}']), T(g[f'ctx{j}'])
+        out = m([lat.to(dev)], t=t.to(dev), context=[ctx.to(dev)], seq_len=int(g['seq_len']))[0]
+        assert out.dtype == torch.float32 and tuple(out.shape) == tuple(lat.shape)
+        # (a) reference fp32 output, stated bf16 tolerance
+        assert rel_l2(out, g[f'out_fp32_{j}']) < 2e-2, (tag, j)
+        # (b) reference under bf16 autocast (same rounding points) — tighter
+        assert rel_l2(out, g[f'out_bf16_{j}']) < 1.2e-2, (tag, j)
+        # (c) our bf16-emulating oracle on the same inputs
+        orc = dit.dit_forward(P, cfg, lat, t, ctx, int(g['seq_len']), emulate_bf16=True)
+        assert rel_l2(out, orc) < 1.2e-2, (tag, j)
+        j += 1
+
+
+def test_dit_context_cache_and_determinism(dev):
+    import wan
+    cfg = W.SMALL_DIT_HD128
+    m = wan.modules.WanModel(**cfg)
+    m.load_state_dict(W.make_dit_params(cfg, 0))
+    m.to(dev)
+    lat = W.randn((16, 2, 8, 12), 20).to(dev)
+    c1, c2 = W.randn((33, 128), 30).to(dev), W.randn((9, 128), 31).to(dev)
+    t = torch.tensor([700], device=dev)
+    a1 = m([lat], t=t, context=[c1], seq_len=48)[0].clone()
+    b1 = m([lat], t=t, context=[c2], seq_len=48)[0].clone()
+    a2 = m([lat], t=t, context=[c1], seq_len=48)[0].clone()     # served from the prompt cache
+    assert torch.equal(a1, a2) and not torch.equal(a1, b1)
+    c1.mul_(2.0)                                                 # in-place edit must invalidate
+    a3 = m([lat], t=t, context=[c1], seq_len=48)[0]
+    assert not torch.equal(a1, a3)
+
+
+# ------------------------------------------------------------------------------------------------
+# schedulers on the GPU (fused lincomb kernel) vs the reference trajectories
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('name,n,shift', [('unipc', 6, 3.0), ('unipc', 2, 5.0), ('dpm', 6, 3.0), ('dpm', 2, 5.0)])
+def test_scheduler_gpu(dev, golden, name, n, shift):
+    from wan.utils import (FlowDPMSolverMultistepScheduler, FlowUniPCMultistepScheduler, get_sampling_sigmas,
+                           retrieve_timesteps)
+    g = golden('g4_schedulers')
+    if name == 'unipc':
+        s = FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)
+        s.set_timesteps(n, device=dev, shift=shift)
+        ts = s.timesteps
+    else:
+        s = FlowDPMSolverMultistepScheduler(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)
+        ts, _ = retrieve_timesteps(s, device=dev, sigmas=get_sampling_sigmas(n, shift))
+    assert np.array_equal(ts.cpu().numpy(), g[f'{name}_t_{n}'])
+    lat = T(g['traj_x0']).to(dev)
+    for i, t in enumerate(ts.tolist()):
+        v = 0.5 * torch.tanh(lat) + 0.1 * math.sin(t / 100.0)
+        lat = s.step(v, t, lat, return_dict=False)[0]
+        assert scale_err(lat, g[f'traj_{name}_{n}'][i]) < 5e-6, (name, i)
+
+
+# ------------------------------------------------------------------------------------------------
+# VAE decode (fp32-exact mode)
+# ------------------------------------------------------------------------------------------------
+def _cl(x):   # [1,C,T,H,W] -> channels-last [T,H,W,C]
+    return x[0].permute(1, 2, 3, 0).contiguous()
+
+
+def test_vae_conv_pieces(dev, golden):
+    from wan.backend import ops
+    g = golden('g5_vae_d8_t3')
+    P = W.make_vae_params(8, 1)
+    w = P['decoder.middle.0.residual.2.weight'].permute(0, 2, 3, 4, 1).contiguous().to(dev)
+    b = P['decoder.middle.0.residual.2.bias'].to(dev)
+    x, c = _cl(T(g['conv_x'])).to(dev), _cl(T(g['conv_cache'])).to(dev)
+    for cache, key in ((None, 'conv_nocache'), (c, 'conv_cache2'), (c[-1:].contiguous(), 'conv_cache1')):
+        out = torch.empty(*x.shape[:3], w.shape[0], dtype=torch.float32, device=dev)
+        ops.vae_conv(x, w, b, out, 3, 3, 3, cache=cache)
+        assert scale_err(out, _cl(T(g[key]))) < 1e-5, key
+
+
+@pytest.mark.parametrize('dim,t', [(8, 3), (8, 5), (32, 2)])
+def test_vae_decode_vs_reference(dev, golden, dim, t):
+    import wan
+    g = golden(f'g5_vae_d{dim}_t{t}')
+    vae = wan.modules.WanVAE(state_dict=W.make_vae_params(dim, 1), device=dev)
+    out = vae.decode([T(g['z']).to(dev)])[0]
+    assert out.dtype == torch.float32 and tuple(out.shape) == g['video'].shape
+    assert out.min() >= -1 and out.max() <= 1
+    assert scale_err(out, g['video']) < 1e-4
+    if t >= 3:   # chunking freedom
+        out2 = vae.model.decode(T(g['z']).to(dev), chunks=[1, t - 1])
+        assert scale_err(out2, g['video']) < 1e-4
+
+
+def test_vae_modules_vs_oracle(dev, golden):
+    """AttentionBlock and Resample pieces against the reference's module outputs."""
+    import wan
+    g = golden('g5_vae_d8_t3')
+    vae = wan.modules.WanVAE(state_dict=W.make_vae_params(8, 1), device=dev).model
+    x = _cl(T(g['conv_x'])).to(dev)
+    assert scale_err(vae._attn('decoder.middle.1.', x), _cl(T(g['attn']))) < 1e-5
+    cache = [None, None]
+    o1 = vae._res('decoder.middle.0.', x[:1], cache, [0])
+    o2 = vae._res('decoder.middle.0.', x[1:], cache, [0])
+    assert scale_err(torch.cat([o1, o2]), _cl(T(g['res_chunked']))) < 1e-5
+    xu = _cl(T(g['up_x'])).to(dev)
+    cache = [None]
+    for i in range(3):
+        o = vae._up('decoder.upsamples.3.', xu[i:i + 1], cache, [0])
+        assert scale_err(o, _cl(T(g[f'up_c{i}']))) < 1e-5, i
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE.json configs[0] end to end through WanT2V.generate
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('solver', ['unipc', 'dpm++'])
+def test_pipeline_cfg1(dev, golden, solver):
+    import wan
+    from wan.configs import Config
+    g = golden('g6_pipeline_cfg1')
+    cfg = W.TINY_DIT
+    model = wan.modules.WanModel(**cfg)
+    model.load_state_dict(W.make_dit_params(cfg, 0))
+    vae = wan.modules.WanVAE(state_dict=W.make_vae_params(8, 1), device=dev)
+    conf = Config(num_train_timesteps=1000, param_dtype=torch.bfloat16, vae_stride=(4, 8, 8), patch_size=(1, 2, 2),
+                  sample_neg_prompt='', vae_checkpoint='', text_len=32)
+    pipe = wan.WanT2V(conf, '', device_id=0, model=model, vae=vae)
+    lats = []
+    video = pipe.generate(T(g['ctx']), size=(64, 64), frame_num=1, shift=5.0, sample_solver=solver, sampling_steps=2,
+                          guide_scale=5.0, n_prompt=T(g['ctx_null']), seed=0, offload_model=False,
+                          noise=T(g['noise']), callback=lambda i, l: lats.append(l.clone()))
+    # final latent vs the reference loop (fp32 reference; bf16 engine) and decoded video
+    assert rel_l2(lats[-1], g[f'x0_{solver}']) < 2e-2
+    assert tuple(video.shape) == (3, 1, 64, 64) and video.dtype == torch.float32
+    if solver == 'unipc':
+        assert rel_l2(video, g['video_unipc']) < 5e-2
+    with pytest.raises(NotImplementedError):
+        pipe.generate(T(g['ctx']), size=(64, 64), frame_num=1, sample_solver='euler', sampling_steps=2,
+                      n_prompt=T(g['ctx_null']), noise=T(g['noise']))
+
+
+# ------------------------------------------------------------------------------------------------
+# size-independent properties at BASELINE.json configs[1] sizes (L = 75 600, 40 heads, d = 5120)
+# ------------------------------------------------------------------------------------------------
+def test_fullsize_attention_properties(dev):
+    from wan.backend import ops
+    L, N = 75600, 40
+    gen = torch.Generator(device=dev).manual_seed(0)
+    q = torch.randn(L, N * 128, device=dev, generator=gen).bfloat16()
+    k = torch.randn(L, N * 128, device=dev, generator=gen).bfloat16()
+    v = torch.randn(L, N * 128, device=dev, generator=gen).bfloat16()
+    Lpad = (L + 63) // 64 * 64
+    vt = torch.empty(N, 128, Lpad, dtype=torch.bfloat16, device=dev)
+    o = torch.empty(L, N * 128, dtype=torch.bfloat16, device=dev)
+    sc = 1 / math.sqrt(128)
+    # (1) rows of softmax sum to one: V = const  =>  O = const, for EVERY query and head
+    ones = torch.full_like(v, 0.5)
+    ops.transpose_v(ones, N, 128, vt)
+    ops.attention_hd128(q, k, vt, o, L, N, sc)
+    assert (o.float() - 0.5).abs().max().item() < 4e-3
+    # (2) permuting the keys (and values with them) does not change the output
+    ops.transpose_v(v, N, 128, vt)
+    ops.attention_hd128(q, k, vt, o, L, N, sc)
+    o1 = o.clone()
+    perm = torch.randperm(L, device=dev, generator=gen)
+    kp, vp = k[perm].contiguous(), v[perm].contiguous()
+    ops.transpose_v(vp, N, 128, vt)
+    ops.attention_hd128(q, kp, vt, o, L, N, sc)
+    assert (o.float() - o1.float()).abs().max().item() < 1e-2
+    # (3) a sampled set of rows against fp32 SDPA-by-hand on the GPU-resident data
+    rows = torch.tensor([0, 1, 255, 256, 40000, 75599], device=dev)
+    for h in (0, 17, 39):
+        qs = q[rows, h * 128:(h + 1) * 128].float()
+        s = (qs @ kp[:, h * 128:(h + 1) * 128].float().T) * sc
+        ref = torch.softmax(s, -1) @ vp[:, h * 128:(h + 1) * 128].float()
+        assert (o[rows, h * 128:(h + 1) * 128].float() - ref).abs().max().item() < 5e-3
+
+
+def test_fullsize_gemm_properties(dev):
+    from wan.backend import ops
+    L, d, f = 75600, 5120, 13824
+    gen = torch.Generator(device=dev).manual_seed(1)
+    a = torch.randn(L, d, device=dev, generator=gen).bfloat16()
+    w = (torch.randn(f, d, device=dev, generator=gen) * 0.02).bfloat16()
+    out = torch.empty(L, f, dtype=torch.bfloat16, device=dev)
+    ops.gemm(a, w, None, ops.BIAS_BF16, out)
+    # sampled rows vs an fp32 matmul of the same bf16 operands
+    rows = torch.tensor([0, 127, 128, 37777, 75599], device=dev)
+    ref = a[rows].float() @ w.float().T
+    assert ((out[rows].float() - ref).abs().max() / ref.abs().max()).item() < 1e-2
+    # residual epilogue is an exact accumulate: x += y twice == x + 2y (fp32 adds of identical bf16 y)
+    x = torch.zeros(L, d, dtype=torch.float32, device=dev)
+    w2 = (torch.randn(d, d, device=dev, generator=gen) * 0.02).bfloat16()
+    ops.gemm(a, w2, None, ops.GATE_RESID_F32, x)
+    x1 = x.clone()
+    ops.gemm(a, w2, None, ops.GATE_RESID_F32, x)
+    assert torch.equal(x, 2 * x1)
