@@ -45,22 +45,22 @@ def flops_per_forward(L, cfg):
             + 2 * L * 64 * d * 2 + 2 * 512 * (4096 * d + d * d))
 
 
-def cpu_baseline(budget_s=20.0):
-    """oracle (CPU restatement, fp32) on a bounded slice: ONE 14B-width block at L=1024
-    (grid 4x16x16), all host cores; extrapolated to steps/s of the 720p workload by FLOPs."""
+def cpu_baseline(budget_s=12.0):
+    """oracle (CPU restatement, fp32) on a bounded slice: ONE 14B-width block at L=512
+    (grid 2x16x16), all host cores; extrapolated to steps/s of the 720p workload by FLOPs."""
     import weights as W
     from oracle import dit
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1))
     cfg = dict(W.TINY_DIT, dim=5120, ffn_dim=13824, num_heads=40, num_layers=1, text_len=512)
     g = torch.Generator().manual_seed(0)
     shapes = {k: v for k, v in W.dit_param_shapes(cfg).items() if k.startswith('blocks.0.')}
     P = {k: (torch.randn(s, generator=g) * 0.02) for k, s in shapes.items()}
-    L = 1024
+    L = 512
     x = torch.randn(L, 5120, generator=g)
     e0 = torch.randn(6, 5120, generator=g) * 0.1
     ctx = torch.randn(512, 5120, generator=g)
     tabs = dit.rope_table(128)
-    run = lambda: dit.block(P, 'blocks.0.', x, e0, L, (4, 16, 16), tabs, ctx, 40, 1e-6, False, False)  # noqa: E731
+    run = lambda: dit.block(P, 'blocks.0.', x, e0, L, (2, 16, 16), tabs, ctx, 40, 1e-6, False, False)  # noqa: E731
     run()
     t0, n = time.time(), 0
     while n < 1 or (time.time() - t0 < budget_s and n < 20):
@@ -73,7 +73,7 @@ def cpu_baseline(budget_s=20.0):
     step_flops = 2 * flops_per_forward(75600, MODEL_14B)
     return {'value': gflops * 1e9 / step_flops, 'unit': 'steps/s', 'cores': torch.get_num_threads(), 'kind': 'port',
             'gflops': round(gflops, 1),
-            'sample': f'oracle/dit.py block (d=5120, 40 heads, ffn=13824) at L=1024, {n} runs of {dt:.2f}s, '
+            'sample': f'oracle/dit.py block (d=5120, 40 heads, ffn=13824) at L=512, {n} runs of {dt:.2f}s, '
                       f'extrapolated to the 720p step (13.05 PFLOP) by the FLOP formula'}
 
 

@@ -76,6 +76,7 @@ __global__ __launch_bounds__(NT) void ln_modulate_kernel(
 extern "C" int mg_ln_modulate(const float* x, int64_t ldx, int64_t rows, int dim, const float* scale,
                               const float* shift, int add_one, float eps, int round_norm_bf16,
                               void* out, int out_f32, int64_t ldo, void* stream) {
+    if (rows == 0) return MG_OK;  // empty input (data pointers of empty tensors are NULL)
     if (!x || !out) return MG_ERR_ARG;
     if (dim <= 0 || (dim & 3) || dim > 8192 || (ldx & 3) || (ldo & 3)) return MG_ERR_SHAPE;
     if (rows <= 0) return MG_OK;
@@ -172,6 +173,7 @@ extern "C" int mg_rmsnorm_rope_bf16(const uint16_t* x, int64_t ldx, uint16_t* ou
                                     int64_t rows, int dim, const float* weight, float eps, int head_dim,
                                     const float* rope_cs, int F, int H, int W, int64_t pos0,
                                     void* stream) {
+    if (rows == 0) return MG_OK;
     if (!x || !out || !weight) return MG_ERR_ARG;
     if (dim <= 0 || (dim & 7) || dim > 8192 || (ldx & 7) || (ldo & 7) || head_dim <= 0 ||
         (head_dim & 7) || dim % head_dim)
