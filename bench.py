@@ -45,12 +45,25 @@ def flops_per_forward(L, cfg):
             + 2 * L * 64 * d * 2 + 2 * 512 * (4096 * d + d * d))
 
 
+def _usable_cores():
+    """host cores this process may really use: affinity, capped by the cgroup CPU quota and at 64
+    (torch's CPU GEMMs stop scaling — and on an over-subscribed container collapse — beyond that)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 64))
+
+
 def cpu_baseline(budget_s=12.0):
     """oracle (CPU restatement, fp32) on a bounded slice: ONE 14B-width block at L=512
     (grid 2x16x16), all host cores; extrapolated to steps/s of the 720p workload by FLOPs."""
     import weights as W
     from oracle import dit
-    torch.set_num_threads(len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1))
+    torch.set_num_threads(_usable_cores())
     cfg = dict(W.TINY_DIT, dim=5120, ffn_dim=13824, num_heads=40, num_layers=1, text_len=512)
     g = torch.Generator().manual_seed(0)
     shapes = {k: v for k, v in W.dit_param_shapes(cfg).items() if k.startswith('blocks.0.')}

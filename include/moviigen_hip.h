@@ -181,8 +181,8 @@ int mg_vae_rmsnorm_silu_f32(const float* x, const float* gamma, float* out, int6
 
 /* Single-head attention over one frame's h*w tokens with head dim C (<=512, %32==0), fp32:
  * AttentionBlock, vae.py:247-256 (scaled_dot_product_attention, scale 1/sqrt(C)).
- * qkv [frames][L][3C] (q|k|v), out [frames][L][C]; workspace: caller-owned L*L + C*L floats
- * (the library never allocates).  L % 4 == 0. */
+ * qkv [frames][L][3C] (q|k|v), out [frames][L][C]; workspace: caller-owned (L + C) * roundup(L, 4)
+ * floats, 16-byte aligned (the library never allocates). */
 int mg_vae_attn_f32(const float* qkv, float* out, int frames, int64_t L, int C, float* workspace,
                     void* stream);
 

@@ -251,9 +251,10 @@ extern "C" int mg_vae_rmsnorm_silu_f32(const float* x, const float* gamma, float
 // AttentionBlock — vae.py:247-256.  S = q k^T / sqrt(C) and o = softmax(S) v as two implicit-GEMM
 // launches around a row softmax; S (L x L fp32) lives in caller workspace.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ s, int64_t L) {
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ s, int64_t L, int64_t ld) {
     __shared__ float red[4];
-    float* row = s + (int64_t)blockIdx.x * L;
+    float* row = s + (int64_t)blockIdx.x * ld;
+    for (int64_t i = L + threadIdx.x; i < ld; i += 256) row[i] = 0.f;  // zero the row padding
     float mx = -3.0e38f;
     for (int64_t i = threadIdx.x; i < L; i += 256) mx = fmaxf(mx, row[i]);
     mx = wave_max(mx);
@@ -272,8 +273,8 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ s
 }
 
 __global__ void transpose_f32_kernel(const float* __restrict__ in, int64_t ldin, float* __restrict__ out,
-                                     int64_t rows, int cols) {
-    // in [rows][cols] (row stride ldin) -> out [cols][rows]
+                                     int64_t rows, int cols, int64_t ldout) {
+    // in [rows][cols] (row stride ldin) -> out [cols][ldout], zero for r in [rows, ldout)
     __shared__ float tile[32][33];
     const int64_t r0 = (int64_t)blockIdx.x * 32;
     const int c0 = blockIdx.y * 32;
@@ -286,32 +287,34 @@ __global__ void transpose_f32_kernel(const float* __restrict__ in, int64_t ldin,
     for (int i = threadIdx.y; i < 32; i += 8) {
         const int c = c0 + i;
         const int64_t r = r0 + threadIdx.x;
-        if (c < cols && r < rows) out[(int64_t)c * rows + r] = tile[threadIdx.x][i];
+        if (c < cols && r < ldout) out[(int64_t)c * ldout + r] = r < rows ? tile[threadIdx.x][i] : 0.f;
     }
 }
 
 extern "C" int mg_vae_attn_f32(const float* qkv, float* out, int frames, int64_t L, int C, float* workspace,
                                void* stream) {
     if (!qkv || !out || !workspace) return MG_ERR_ARG;
-    if (frames <= 0 || L <= 0 || (L & 3) || C <= 0 || (C & 3) || L > 0x7fffffffLL) return MG_ERR_SHAPE;
+    if (frames <= 0 || L <= 0 || C <= 0 || (C & 3) || L > 0x7ffffff0LL) return MG_ERR_SHAPE;
+    if ((uintptr_t)workspace & 15) return MG_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
-    float* S = workspace;                 // [L][L]
-    float* vT = workspace + L * L;        // [C][L]
+    const int64_t Lp = (L + 3) & ~(int64_t)3;  // row stride of S / V^T, 16-byte aligned rows
+    float* S = workspace;                 // [L][Lp]
+    float* vT = workspace + L * Lp;       // [C][Lp]
     for (int f = 0; f < frames; ++f) {
         const float* base = qkv + (int64_t)f * L * 3 * C;
         ConvArgs a;
         // S[L][L] = q[L][C] . k[L][C]^T * C^-1/2
         a.x = base; a.cache = nullptr; a.tc = 0; a.T = 1; a.H = 1; a.W = (int)L; a.Cin = C; a.ldx = 3 * C;
         a.w = base + C; a.ldw = 3 * C; a.bias = nullptr; a.Cout = (int)L; a.kt = a.kh = a.kw = 1; a.up2 = 0;
-        a.residual = nullptr; a.out = S; a.ldo = L; a.Ho = 1; a.Wo = (int)L; a.M = L;
+        a.residual = nullptr; a.out = S; a.ldo = Lp; a.Ho = 1; a.Wo = (int)L; a.M = L;
         a.out_scale = 1.f / sqrtf((float)C);
         int rc = launch_conv(a, st);
         if (rc) return rc;
-        hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)L), dim3(256), 0, st, S, L);
-        hipLaunchKernelGGL(transpose_f32_kernel, dim3((unsigned)((L + 31) / 32), (unsigned)((C + 31) / 32)),
-                           dim3(32, 8), 0, st, base + 2 * C, (int64_t)3 * C, vT, L, C);
-        // out[L][C] = P[L][L] . vT[C][L]^T
-        a.x = S; a.ldx = L; a.Cin = (int)L; a.w = vT; a.ldw = L; a.Cout = C; a.out = out + (int64_t)f * L * C;
+        hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)L), dim3(256), 0, st, S, L, Lp);
+        hipLaunchKernelGGL(transpose_f32_kernel, dim3((unsigned)((Lp + 31) / 32), (unsigned)((C + 31) / 32)),
+                           dim3(32, 8), 0, st, base + 2 * C, (int64_t)3 * C, vT, L, C, Lp);
+        // out[L][C] = P[L][Lp] . vT[C][Lp]^T   (padding columns are zero on both sides)
+        a.x = S; a.ldx = Lp; a.Cin = (int)Lp; a.w = vT; a.ldw = Lp; a.Cout = C; a.out = out + (int64_t)f * L * C;
         a.ldo = C; a.out_scale = 1.f;
         rc = launch_conv(a, st);
         if (rc) return rc;

@@ -1,0 +1,37 @@
+"""Time WanVAE decode (BASELINE.json configs[4]: 1920x832x81f latent -> pixels) on one MI355X.
+    python tools/bench_vae.py [--size 1920x832] [--frames 81] [--chunk N]
+Synthetic weights of the shipped decoder shape (dim 96), z = randn seed 7."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'moviigen1.1_amd'), os.path.join(ROOT, 'tests', 'golden')):
+    sys.path.insert(0, p)
+import torch  # noqa: E402
+import weights as W  # noqa: E402
+import wan  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--size', default='1920x832')
+ap.add_argument('--frames', type=int, default=81)
+ap.add_argument('--chunk', type=int, default=1, help='latent frames per decoder chunk after the first')
+args = ap.parse_args()
+Wd, Hd = (int(v) for v in args.size.split('x'))
+T = (args.frames - 1) // 4 + 1
+dev = torch.device('cuda:0')
+vae = wan.modules.WanVAE(state_dict=W.make_vae_params(96, 1), device=dev)
+z = torch.randn(16, T, Hd // 8, Wd // 8, generator=torch.Generator().manual_seed(7)).to(dev)
+chunks = [1] + [args.chunk] * ((T - 1) // args.chunk) + ([(T - 1) % args.chunk] if (T - 1) % args.chunk else [])
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+video = vae.model.decode(z, chunks=chunks)
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+# conv FLOPs of the decoder at this size (1116.5 TF at 1920x832x81, scales with voxels)
+flops = 1116.5e12 * (Wd * Hd * args.frames) / (1920 * 832 * 81)
+print(json.dumps({'metric': 'vae_decode_sec', 'value': dt, 'size': args.size, 'frames': args.frames, 'chunks': chunks[:3],
+                  'tflops_fp32': flops / dt / 1e12, 'fp32_mfma_peak_tflops': 157.3, 'frac': flops / dt / 157.3e12,
+                  'finite': bool(torch.isfinite(video).all().item()), 'peak_mem_gb': torch.cuda.max_memory_allocated() / 2**30}))
