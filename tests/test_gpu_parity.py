@@ -401,3 +401,17 @@ def test_fullsize_gemm_properties(dev):
     x1 = x.clone()
     ops.gemm(a, w2, None, ops.GATE_RESID_F32, x)
     assert torch.equal(x, 2 * x1)
+
+
+def test_sequence_parallel_two_ranks_one_gpu():
+    """Ulysses path end to end with world_size 2 (both ranks on cuda:0, gloo transport):
+    sharded forward == unsharded forward, bit for bit."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
+                        '--master-addr', '127.0.0.1', '--master-port', '29551',
+                        os.path.join(root, 'tests', 'dist_sp_worker.py')], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert 'SP_OK rank0' in r.stdout and 'SP_OK rank1' in r.stdout
