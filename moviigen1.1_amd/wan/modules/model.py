@@ -225,21 +225,34 @@ class WanModel(nn.Module):
             raise RuntimeError('WanModel.forward needs the model on a HIP device (model.to("cuda")): the hot '
                                'path has no CPU implementation — use oracle/ for CPU reference numbers')
         pk = {'layers': []}
+        sharded = getattr(self, '_shards', None) is not None
         for b in self.blocks:
             sa, ca = b.self_attn, b.cross_attn
-            wqkv = torch.cat([sa.q.weight, sa.k.weight, sa.v.weight], 0).contiguous()
-            # re-point the three parameters at the fused storage: no second copy of the weights
-            d = self.dim
-            sa.q.weight.data, sa.k.weight.data, sa.v.weight.data = wqkv[:d], wqkv[d:2 * d], wqkv[2 * d:]
-            wkv = torch.cat([ca.k.weight, ca.v.weight], 0).contiguous()
-            ca.k.weight.data, ca.v.weight.data = wkv[:d], wkv[d:]
-            pk['layers'].append(dict(
-                wqkv=wqkv, bqkv=torch.cat([sa.q.bias, sa.k.bias, sa.v.bias]).contiguous(),
-                wkv_c=wkv, bkv_c=torch.cat([ca.k.bias, ca.v.bias]).contiguous()))
+            lw = dict(bqkv=torch.cat([sa.q.bias, sa.k.bias, sa.v.bias]).contiguous(),
+                      bkv_c=torch.cat([ca.k.bias, ca.v.bias]).contiguous())
+            if not sharded:
+                wqkv = torch.cat([sa.q.weight, sa.k.weight, sa.v.weight], 0).contiguous()
+                # re-point the three parameters at the fused storage: no second copy of the weights
+                d = self.dim
+                sa.q.weight.data, sa.k.weight.data, sa.v.weight.data = wqkv[:d], wqkv[d:2 * d], wqkv[2 * d:]
+                wkv = torch.cat([ca.k.weight, ca.v.weight], 0).contiguous()
+                ca.k.weight.data, ca.v.weight.data = wkv[:d], wkv[d:]
+                lw.update({'wqkv': wqkv, 'wkv_c': wkv, 'self_attn.o': sa.o.weight, 'cross_attn.q': ca.q.weight,
+                           'cross_attn.o': ca.o.weight, 'ffn.0': b.ffn['0'].weight, 'ffn.2': b.ffn['2'].weight})
+            pk['layers'].append(lw)
         pk['modulation'] = torch.cat([b.modulation.data.reshape(6, self.dim) for b in self.blocks], 0).contiguous()
         pk['patch_w'] = self.patch_embedding.weight.data.reshape(self.dim, -1)
         self._packed = pk
         return pk
+
+    def _layer(self, i):
+        """GEMM operands of block i: resident, or (block-sharded mode, wan.distributed.fsdp) views of
+        the all-gather buffer, with block i+1's gather already in flight on the comm stream."""
+        lw = self._pack()['layers'][i]
+        sh = getattr(self, '_shards', None)
+        if sh is None:
+            return lw
+        return {**lw, **sh.fetch(i)}
 
     def _workspace(self, L, dev):
         key = (L, str(dev))
@@ -294,7 +307,8 @@ class WanModel(nn.Module):
         kv = torch.empty(Lc, 2 * d, dtype=bf, device=dev)
         layers = []
         Lcpad = (Lc + 63) // 64 * 64
-        for b, lw in zip(self.blocks, pk['layers']):
+        for li, b in enumerate(self.blocks):
+            lw = self._layer(li)
             ops.gemm(emb, lw['wkv_c'], lw['bkv_c'], ops.BIAS_BF16, kv)
             kc = torch.empty(Lc, d, dtype=bf, device=dev)
             ops.rmsnorm_rope(kv[:, :d], b.cross_attn.norm_k.weight, self.eps, hd, kc)
@@ -394,25 +408,26 @@ class WanModel(nn.Module):
         rope = self._rope_tab(grid, dev)
         mod = ws['mod']
 
-        for i, (blk, lw) in enumerate(zip(self.blocks, pk['layers'])):
+        for i, blk in enumerate(self.blocks):
+            lw = self._layer(i)
             m = mod[6 * i:6 * i + 6]
             # self attention
             ops.ln_modulate(x, m[1], m[0], True, eps, ws['h'], round_norm_bf16=(i == 0))
             ops.gemm(ws['h'], lw['wqkv'], lw['bqkv'], ops.BIAS_BF16, ws['qkv'])
             self._self_attention(ws, blk, grid, rope, L, pos0)
-            ops.gemm(ws['a'], blk.self_attn.o.weight, blk.self_attn.o.bias, ops.GATE_RESID_F32, x, gate=m[2])
+            ops.gemm(ws['a'], lw['self_attn.o'], blk.self_attn.o.bias, ops.GATE_RESID_F32, x, gate=m[2])
             # cross attention (text keys/values cached per prompt)
             ca = blk.cross_attn
             kc, vc = ctx_layers[i]
             ops.ln_modulate(x, blk.norm3.weight, blk.norm3.bias, False, eps, ws['h'])
-            ops.gemm(ws['h'], ca.q.weight, ca.q.bias, ops.BIAS_BF16, ws['q'])
+            ops.gemm(ws['h'], lw['cross_attn.q'], ca.q.bias, ops.BIAS_BF16, ws['q'])
             ops.rmsnorm_rope(ws['q'], ca.norm_q.weight, eps, d // self.num_heads, ws['k'])
             self._attention(ws['k'], kc, vc, ws['a'], self.text_len, self.num_heads)
-            ops.gemm(ws['a'], ca.o.weight, ca.o.bias, ops.GATE_RESID_F32, x, gate=None)
+            ops.gemm(ws['a'], lw['cross_attn.o'], ca.o.bias, ops.GATE_RESID_F32, x, gate=None)
             # ffn
             ops.ln_modulate(x, m[4], m[3], True, eps, ws['h'])
-            ops.gemm(ws['h'], blk.ffn['0'].weight, blk.ffn['0'].bias, ops.BIAS_GELU_BF16, ws['u'])
-            ops.gemm(ws['u'], blk.ffn['2'].weight, blk.ffn['2'].bias, ops.GATE_RESID_F32, x, gate=m[5])
+            ops.gemm(ws['h'], lw['ffn.0'], blk.ffn['0'].bias, ops.BIAS_GELU_BF16, ws['u'])
+            ops.gemm(ws['u'], lw['ffn.2'], blk.ffn['2'].bias, ops.GATE_RESID_F32, x, gate=m[5])
 
         # head (model.py:333-343): fp32 end to end
         ops.ln_modulate(x, ws['hmod'][1], ws['hmod'][0], True, eps, ws['hf'])

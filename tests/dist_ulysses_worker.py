@@ -1,4 +1,5 @@
-"""worker for test_ulysses_gloo_world2 (launched by torch.distributed.run, backend gloo)."""
+"""worker for the CPU multi-process tests (launched by torch.distributed.run, backend gloo,
+world_size 2): Ulysses data movement and block-sharded weights."""
 import os
 import sys
 
@@ -8,8 +9,10 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'moviigen1.1_amd'), os.path.join(ROOT, 'tests', 'golden')]
 
+import weights as W  # noqa: E402
 from oracle import dit  # noqa: E402
-from wan.distributed import ulysses  # noqa: E402
+import wan  # noqa: E402
+from wan.distributed import fsdp, ulysses  # noqa: E402
 
 dist.init_process_group('gloo')
 rank, P = dist.get_rank(), dist.get_world_size()
@@ -34,4 +37,30 @@ assert torch.equal(back.view(L // P, N, hd), sim_back[rank])
 gath = ulysses.all_gather_seq(full[rank], dist.group.WORLD, P)
 assert torch.equal(gath, torch.cat(full, 0)), 'all_gather_seq'
 print(f'ULYSSES_OK rank{rank}', flush=True)
+
+# ---- block-sharded weights: every rank keeps 1/P, fetch(i) reassembles block i exactly -------------
+cfg = dict(W.TINY_DIT, num_layers=3)
+Pm = W.make_dit_params(cfg, 0)
+m = wan.modules.WanModel(**cfg)
+m.load_state_dict(Pm)
+if rank == 1:  # sync_module_states must overwrite rank 1's (deliberately different) weights
+    for p in m.parameters():
+        if p.dtype == torch.bfloat16:
+            p.data.add_(1.0)
+fsdp.shard_model(m, device_id=None)
+sh = m._shards
+per_rank = sum(s.numel() for s in sh.shards)
+total = sum(Pm[f'blocks.{i}.{n}.weight'].numel() for i in range(3) for n in fsdp.ORDER)
+assert per_rank * P >= total and per_rank * P < total + 3 * P * 8
+assert m.blocks[0].ffn['0'].weight.numel() == 0          # full copies released
+for rep in range(2):
+    for i in range(3):
+        v = sh.fetch(i)
+        for n in fsdp.ORDER:
+            ref = Pm[f'blocks.{i}.{n}.weight'].to(torch.bfloat16)
+            assert torch.equal(v[n], ref), (i, n)
+        d = cfg['dim']
+        assert torch.equal(v['wqkv'][d:2 * d], Pm[f'blocks.{i}.self_attn.k.weight'].to(torch.bfloat16))
+        assert torch.equal(v['wkv_c'][d:], Pm[f'blocks.{i}.cross_attn.v.weight'].to(torch.bfloat16))
+print(f'SHARDS_OK rank{rank}', flush=True)
 dist.destroy_process_group()
