@@ -113,6 +113,10 @@ int mg_attn_fwd_bf16_generic(const uint16_t* q, int64_t ldq, const uint16_t* k, 
 /* Tuning knob: 1 (default) = defer the online-softmax rescale while no row maximum grew by more
  * than 2^8 since the last rescale (P <= 256 in bf16); 0 = rescale every tile. */
 void mg_attn_set_lazy_rescale(int on);
+/* Schedule of mg_attn_fwd_bf16_hd128: 0 (default) = lock-step; 1 = ping-pong (two wave groups half a tile out of
+ * phase: one in its MFMA segment while the other does softmax; measured slower, kept as an
+ * experiment). Same results. */
+void mg_attn_set_variant(int variant);
 
 /* ------------------------------------------------------------------------------------------
  * DiT — small fp32 pieces (time embedding, head, patch gather, latent algebra)

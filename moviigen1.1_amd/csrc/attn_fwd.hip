@@ -112,6 +112,12 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_hd128_kernel(
     const int nkv = (int)((Lk + ATT_KV - 1) / ATT_KV);
     load_tile(0);
     store_tile(0);
+    // Retire the Q-fragment loads HERE: an (empty) consumer of every fragment makes hipcc place
+    // its vmcnt wait before the loop.  Otherwise the loop body inherits "Q may still be in
+    // flight" and guards every S^T MFMA with s_waitcnt vmcnt(7..0) — which in steady state
+    // drains the NEXT tile's prefetch at the top of each iteration instead of under the MFMAs.
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) asm volatile("" : "+v"(qf[kk]));
     __syncthreads();
 
     for (int t = 0; t < nkv; ++t) {
@@ -222,8 +228,14 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_hd128_kernel(
     }
 }
 
+int mg_attn_pp_launch(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk, const uint16_t* vt,
+                      int64_t ldvt, uint16_t* o, int64_t ldo, int64_t Lq, int64_t Lk, int heads, float c_log2,
+                      int nqb, int lazy, hipStream_t st);  // attn_fwd_pp.hip
+
 static int g_attn_lazy = 1;
+static int g_attn_variant = 0;  // 0 = lock-step schedule (this file, fastest: 969 TF/s), 1 = ping-pong (attn_fwd_pp.hip, 829 TF/s)
 extern "C" void mg_attn_set_lazy_rescale(int on) { g_attn_lazy = on; }
+extern "C" void mg_attn_set_variant(int v) { g_attn_variant = v; }
 
 extern "C" int mg_attn_fwd_bf16_hd128(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk,
                                       const uint16_t* vt, int64_t ldvt, uint16_t* o, int64_t ldo,
@@ -240,6 +252,8 @@ extern "C" int mg_attn_fwd_bf16_hd128(const uint16_t* q, int64_t ldq, const uint
     const float c_log2 = scale * 1.4426950408889634f;
     const dim3 grid((unsigned)(nqb * heads)), block(ATT_THREADS);
     hipStream_t st = (hipStream_t)stream;
+    if (g_attn_variant == 1)
+        return mg_attn_pp_launch(q, ldq, k, ldk, vt, ldvt, o, ldo, Lq, Lk, heads, c_log2, nqb, g_attn_lazy, st);
     if (g_attn_lazy)
         hipLaunchKernelGGL(attn_fwd_hd128_kernel<true>, grid, block, 0, st, q, ldq, k, ldk, vt, ldvt, o, ldo,
                            Lq, Lk, heads, c_log2, nqb);

@@ -19,17 +19,16 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 
 #define MG_DEV static __device__ __forceinline__
 
-// fp32 -> bf16 round-to-nearest-even (matches torch .to(bfloat16) for finite values)
-MG_DEV unsigned short f2bf(float f) {
-    unsigned int u = __float_as_uint(f);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
-MG_DEV float bf2f(unsigned short h) { return __uint_as_float(((unsigned int)h) << 16); }
-MG_DEV float round_bf(float f) { return bf2f(f2bf(f)); }
+// fp32 -> bf16 round-to-nearest-even (matches torch .to(bfloat16)); one v_cvt_pk_bf16_f32 per pair
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 MG_DEV unsigned int pack_bf2(float lo, float hi) {
-    return (unsigned int)f2bf(lo) | ((unsigned int)f2bf(hi) << 16);
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2_t));
 }
+MG_DEV unsigned short f2bf(float f) { return (unsigned short)(pack_bf2(f, 0.f) & 0xffffu); }
+MG_DEV float bf2f(unsigned short h) { return __uint_as_float(((unsigned int)h) << 16); }
+MG_DEV float round_bf(float f) { return __uint_as_float(pack_bf2(f, 0.f) << 16); }
 
 MG_DEV float wave_sum(float v) {
 #pragma unroll

@@ -436,6 +436,31 @@ int main(int argc, char** argv) {
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
     printf("device: %s  CUs=%d  %s  abi=%d\n", prop.name, prop.multiProcessorCount, mg_version(), mg_abi_version());
+    if (argc > 1 && !strcmp(argv[1], "attn")) {  // quick perf loop on the dominant kernel
+        for (int variant = 0; variant < 2; ++variant) {
+            printf("== attention variant %d ==\n", variant);
+            mg_attn_set_variant(variant);
+            test_attn(300, 300, 2, 0, false, 1);
+            test_attn(300, 300, 2, 0, false, 0);
+            test_attn(64, 64, 1, 0, false, 1);
+            test_attn(700, 512, 3, 0, false, 1);
+            test_attn(1000, 77, 1, 0, false, 1);
+            test_attn(75600, 75600, 8, 24, true, 1);
+            test_attn(75600, 512, 40, 24, true, 1);
+        }
+        printf("%s: %d failure(s)\n", n_fail ? "SELFTEST FAILED" : "SELFTEST OK", n_fail);
+        return n_fail ? 1 : 0;
+    }
+    if (argc > 1 && !strcmp(argv[1], "gemm")) {
+        test_gemm(300, 256, 128, 0, 0, false);
+        test_gemm(129, 200, 192, 2, 0, false);
+        test_gemm(75600, 5120, 5120, 0, 128, true);
+        test_gemm(75600, 13824, 5120, 1, 128, true);
+        test_gemm(75600, 5120, 13824, 2, 128, true);
+        test_gemm(8192, 8192, 8192, 0, 128, true);
+        printf("%s: %d failure(s)\n", n_fail ? "SELFTEST FAILED" : "SELFTEST OK", n_fail);
+        return n_fail ? 1 : 0;
+    }
 
     test_small();
     test_ln(37, 5120, 1, 0, 0);
