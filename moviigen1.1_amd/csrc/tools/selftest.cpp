@@ -451,6 +451,15 @@ int main(int argc, char** argv) {
         printf("%s: %d failure(s)\n", n_fail ? "SELFTEST FAILED" : "SELFTEST OK", n_fail);
         return n_fail ? 1 : 0;
     }
+    if (argc > 1 && !strcmp(argv[1], "attn1")) {  // single big launch set, for rocprofv3 --pmc passes
+        mg_attn_set_variant(argc > 2 ? atoi(argv[2]) : 0);
+        test_attn(75600, 75600, 8, 8, true, 1);
+        return n_fail ? 1 : 0;
+    }
+    if (argc > 1 && !strcmp(argv[1], "gemm1")) {
+        test_gemm(75600, 5120, 5120, 0, 64, true);
+        return n_fail ? 1 : 0;
+    }
     if (argc > 1 && !strcmp(argv[1], "gemm")) {
         test_gemm(300, 256, 128, 0, 0, false);
         test_gemm(129, 200, 192, 2, 0, false);
