@@ -92,6 +92,10 @@ int mg_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw,
                  const float* bias, int64_t M, int N, int K, int epilogue, void* out,
                  int64_t ldo, const float* gate, void* stream);
 
+/* Tile schedule of mg_gemm_bf16: 2 (default) = 256x128x64 tile, 8 waves, 3-stage LDS ring with
+ * counted vmcnt; 1 = 128x128x64 tile, 4 waves, 2 stages.  Same results bit for bit. */
+void mg_gemm_set_variant(int variant);
+
 /* softmax(q k^T * scale) v, non-causal, keys >= Lk masked; bf16 in/out, fp32 accumulate,
  * head_dim 128.  Replaces flash_attn_varlen_func as called from
  * wan/modules/attention.py:96-127 (self-attention model.py:146-151, k_lens=seq_lens;

@@ -461,12 +461,19 @@ int main(int argc, char** argv) {
         return n_fail ? 1 : 0;
     }
     if (argc > 1 && !strcmp(argv[1], "gemm")) {
-        test_gemm(300, 256, 128, 0, 0, false);
-        test_gemm(129, 200, 192, 2, 0, false);
-        test_gemm(75600, 5120, 5120, 0, 128, true);
-        test_gemm(75600, 13824, 5120, 1, 128, true);
-        test_gemm(75600, 5120, 13824, 2, 128, true);
-        test_gemm(8192, 8192, 8192, 0, 128, true);
+        for (int variant = 1; variant <= 2; ++variant) {
+            printf("== gemm variant %d ==\n", variant);
+            mg_gemm_set_variant(variant);
+            for (int epi = 0; epi < 4; ++epi) test_gemm(300, 256, 128, epi, 0, false);
+            test_gemm(129, 200, 192, 2, 0, false);
+            test_gemm(257, 128, 64, 0, 0, false);
+            test_gemm(1000, 1280, 1024, 2, 0, false);
+            test_gemm(515, 64, 5120, 3, 0, false);
+            test_gemm(75600, 5120, 5120, 0, 128, true);
+            test_gemm(75600, 13824, 5120, 1, 128, true);
+            test_gemm(75600, 5120, 13824, 2, 128, true);
+            test_gemm(8192, 8192, 8192, 0, 128, true);
+        }
         printf("%s: %d failure(s)\n", n_fail ? "SELFTEST FAILED" : "SELFTEST OK", n_fail);
         return n_fail ? 1 : 0;
     }

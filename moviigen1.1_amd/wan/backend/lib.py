@@ -25,6 +25,7 @@ SIGNATURES = {
                                  c_f32, c_vp],
     'mg_attn_set_lazy_rescale': [c_int],
     'mg_attn_set_variant': [c_int],
+    'mg_gemm_set_variant': [c_int],
     'mg_sinusoid_embed': [c_vp, c_int, c_int, c_int, c_vp, c_vp],
     'mg_gemv_f32': [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp],
     'mg_add_rows_f32': [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp],
@@ -41,7 +42,8 @@ SIGNATURES = {
     'mg_vae_video_out_f32': [c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_int, c_vp],
     'mg_vae_time_interleave_f32': [c_vp, c_int, c_i64, c_int, c_vp, c_vp],
 }
-_RESTYPE = {'mg_version': ctypes.c_char_p, 'mg_attn_set_lazy_rescale': None, 'mg_attn_set_variant': None}
+_RESTYPE = {'mg_version': ctypes.c_char_p, 'mg_attn_set_lazy_rescale': None, 'mg_attn_set_variant': None,
+            'mg_gemm_set_variant': None}
 
 ERRORS = {-1: 'MG_ERR_ARG (null pointer / bad enum)', -2: 'MG_ERR_SHAPE (unsupported shape or alignment)',
           -3: 'MG_ERR_LAUNCH (kernel launch failed)'}
