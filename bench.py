@@ -210,6 +210,16 @@ def main():
                          'launches_timed': len(attn_events), 'ms_per_launch': attn_ms,
                          'algorithmic_flops_per_launch': attn_flops},
         }
+        # HBM-side traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this same
+        # command (tools/round_end_gpu.sh); the newest committed summary is reported, never a guess
+        if args.workload == '720p' and world == 1 and not args.layers:
+            import glob
+            found = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*pmc_traffic.json')))
+            if found:
+                with open(found[-1]) as f:
+                    pmc = json.load(f)
+                line['roofline']['traffic'] = pmc.get('traffic_bytes_per_launch')
+                line['roofline']['traffic_unit'] = 'bytes/launch (FETCH_SIZE x2 + WRITE_SIZE, ' + os.path.basename(found[-1]) + ')'
         if args.layers or args.workload == 'tiny':
             line['invalid'] = 'debug configuration (not the BASELINE model)'
         if world == 1 and not args.no_cpu_baseline:
