@@ -64,12 +64,15 @@ int mg_rmsnorm_rope_bf16(const uint16_t* x, int64_t ldx, uint16_t* out, int64_t 
                          int64_t rows, int dim, const float* weight, float eps, int head_dim,
                          const float* rope_cs, int F, int H, int W, int64_t pos0, void* stream);
 
-/* v [L][heads*head_dim] (row stride ldv) -> vt [heads][head_dim][Lpad], zero-filled for keys
- * in [L, Lpad).  Layout contract of mg_attn_fwd_bf16_hd128 (keys contiguous for the P.V MFMA
- * A-operand); no reference counterpart (flash_attn hides its own V staging).
- * head_dim == 128, Lpad % 64 == 0, Lpad >= L. */
-int mg_transpose_v_bf16(const uint16_t* v, int64_t ldv, int64_t L, int heads, int head_dim,
-                        uint16_t* vt, int64_t Lpad, void* stream);
+/* Pack K and/or V (row-major [L][>=heads*128], row strides ldk/ldv; either may be NULL) into the
+ * per-64-key-tile operand layout of mg_attn_fwd_bf16_hd128, nt = ceil(L/64) tiles per head:
+ *     kp[head][tile][c = d/8 (16)][r = key%64 (64)][8]
+ *     vp[head][tile][kc = (key%64)/8 (8)][d (128)][8 keys]
+ * each tile = one contiguous 16 KiB block = the LDS image (pure LDS-DMA staging, conflict-free
+ * ds_read_b128 with immediate offsets); keys >= L are zero.  kp/vp: heads*nt*8192 elements each,
+ * 16-byte aligned.  No reference counterpart (flash_attn stages K/V inside its kernel). */
+int mg_pack_kv_bf16(const uint16_t* k, int64_t ldk, const uint16_t* v, int64_t ldv, int64_t L,
+                    int heads, int head_dim, uint16_t* kp, uint16_t* vp, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * DiT — MFMA kernels
@@ -100,12 +103,11 @@ void mg_gemm_set_variant(int variant);
  * head_dim 128.  Replaces flash_attn_varlen_func as called from
  * wan/modules/attention.py:96-127 (self-attention model.py:146-151, k_lens=seq_lens;
  * cross-attention model.py:176, Lk = 512 unmasked).
- *   q [Lq][>=heads*128] row stride ldq; k [Lk][..] row stride ldk; head h at column h*128
- *   vt [heads][128][ldvt] from mg_transpose_v_bf16 (ldvt % 64 == 0, ldvt >= Lk, zero padded)
- *   o [Lq][..] row stride ldo. */
-int mg_attn_fwd_bf16_hd128(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk,
-                           const uint16_t* vt, int64_t ldvt, uint16_t* o, int64_t ldo,
-                           int64_t Lq, int64_t Lk, int heads, float scale, void* stream);
+ *   q [Lq][>=heads*128] row stride ldq, head h at column h*128; o likewise (row stride ldo)
+ *   kp, vp: K and V of the Lk keys packed by mg_pack_kv_bf16(…, L = Lk, …). */
+int mg_attn_fwd_bf16_hd128(const uint16_t* q, int64_t ldq, const uint16_t* kp, const uint16_t* vp,
+                           uint16_t* o, int64_t ldo, int64_t Lq, int64_t Lk, int heads, float scale,
+                           void* stream);
 
 /* Same contract for any head_dim <= 256 (head_dim % 8 == 0): the correctness path for model
  * sizes whose head_dim is not 128 (BASELINE.json configs[0]: head_dim 32).  v is NOT transposed:
@@ -117,9 +119,11 @@ int mg_attn_fwd_bf16_generic(const uint16_t* q, int64_t ldq, const uint16_t* k, 
 /* Tuning knob: 1 (default) = defer the online-softmax rescale while no row maximum grew by more
  * than 2^8 since the last rescale (P <= 256 in bf16); 0 = rescale every tile. */
 void mg_attn_set_lazy_rescale(int on);
-/* Schedule of mg_attn_fwd_bf16_hd128: 0 (default) = lock-step; 1 = ping-pong (two wave groups half a tile out of
- * phase: one in its MFMA segment while the other does softmax; measured slower, kept as an
- * experiment). Same results. */
+/* Schedule of mg_attn_fwd_bf16_hd128, two bits.  bit 0: 0 = lock-step (8 waves in the same phase),
+ * 1 = ping-pong (waves 4-7 one barrier interval behind waves 0-3: on each SIMD one wave is in its
+ * 32-MFMA matrix segment while its partner does softmax).  bit 1: 0 = LDS fragment reads scheduled
+ * by hipcc, 1 = hand-issued (inline-asm ds_read_b128 ring with counted lgkmcnt).  Same math in all
+ * four; default 0 = the fastest measured. */
 void mg_attn_set_variant(int variant);
 
 /* ------------------------------------------------------------------------------------------

@@ -1,0 +1,423 @@
+// Flash-style attention forward, head_dim 128, non-causal, bf16 in/out, fp32 accumulate — gfx950.
+//
+// Replaces flash_attn_varlen_func as the reference calls it (wan/modules/attention.py:96-127)
+// from WanSelfAttention (wan/modules/model.py:146-151; L = 75 600 .. 166 320 keys) and
+// WanT2VCrossAttention (model.py:176; 512 keys).  72-85 % of all FLOPs of the path.
+//
+// Operand layout (ABI 2).  Q and O are row-major [L][heads*128].  K and V arrive PRE-PACKED per
+// 64-key tile (mg_pack_kv_bf16, one pass per layer, 0.2 % of the attention time):
+//     kp[head][tile][c = d/8 (16)][r = key%64][8]      vp[head][tile][kc = (key%64)/8 (8)][d (128)][8]
+// i.e. every tile is one contiguous 16 KiB block whose byte image IS the LDS image:
+//   * staging is a pure contiguous LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave instruction,
+//     fully coalesced) — no staging VGPRs, no ds_write pass, no swizzle arithmetic;
+//   * an MFMA fragment is the 16-byte chunk (c, row): lanes of a ds_read_b128 group read
+//     different rows of the SAME chunk column = 16 consecutive 16-byte slots: conflict-free by
+//     construction, and the address is ONE per-lane base (row*16 [+ g*chunk-stride]) plus an
+//     immediate — the XOR-swizzled row-major image of ABI 1 needed a separate address VGPR per
+//     (fragment, slot) and ~17 VALU ops per tile to form them.
+//
+// Math (all schedules):  S^T = K.Q^T with K as the MFMA A-operand and Q^T (registers, whole
+// kernel) as B: a lane owns ONE query, softmax statistics are per-lane scalars.  K rows enter the
+// MFMA permuted (row bits 2<->3) so a lane's 8 consecutive accumulator registers are 8 consecutive
+// keys: P (bf16) is directly the B-operand of O^T = V^T.P^T, the A-operand the chunk
+// vp[kc][d] = V[8 keys][d].  Deferred rescale of O^T while no row maximum grew by 2^8.
+//
+// Schedules (mg_attn_set_variant):
+//   0  lock-step : 8 waves x 32 queries, one barrier per tile, all waves in the same phase.
+//   1  ping-pong : same tiling; waves 4-7 run one barrier interval behind waves 0-3, every interval
+//                  is either a vector segment (softmax of tile t) or a matrix segment
+//                  (P.V(t) ; S^T(t+1), 32 MFMAs, fragment reads DEPTH ahead): on each SIMD one wave
+//                  feeds the matrix pipe while its partner does softmax.
+#include <type_traits>
+#include "common.h"
+#include "../../include/moviigen_hip.h"
+
+#define ATT_THREADS 512
+#define ATT_QB 256
+#define ATT_KV 64
+#define TILE_BYTES 16384
+#define K_OFF(slot) ((slot) * TILE_BYTES)
+#define V_OFF(slot) (2 * TILE_BYTES + (slot) * TILE_BYTES)
+
+typedef const __attribute__((address_space(1))) void* att_gptr_t;
+typedef __attribute__((address_space(3))) void* att_lptr_t;
+
+MG_DEV bf16x8_t att_bf(u32x4_t v) { return __builtin_bit_cast(bf16x8_t, v); }
+MG_DEV void att_glds16(const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((att_gptr_t)g, (att_lptr_t)l, 16, 0, 0);
+}
+
+struct AttState {
+    f32x16_t ot[4];
+    f32x16_t st[2];
+    bf16x8_t pf[2][2];
+    float m_run, l_run;
+};
+
+// online softmax of one 64-key tile: st -> pf, (m, l) update, deferred rescale of ot
+template <bool LAZY>
+MG_DEV void att_softmax(AttState& s, int lim, int g, float c_log2) {
+    if (lim < ATT_KV) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kb * 32 + (r >> 3) * 16 + g * 8 + (r & 7);
+                if (key >= lim) s.st[kb][r] = -1e30f;
+            }
+    }
+    float tmax = s.st[0][0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s.st[0][r]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s.st[1][r]);
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    float m_new = fmaxf(s.m_run, tmax);
+    bool rescale = true;
+    if (LAZY) {
+        rescale = !__all((tmax - s.m_run) * c_log2 <= 8.f);
+        if (!rescale) m_new = s.m_run;
+    }
+    const float mc = m_new * c_log2;
+    float psum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        float p[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            p[r] = __builtin_amdgcn_exp2f(s.st[kb][r] * c_log2 - mc);
+            psum += p[r];
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            u32x4_t w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] = pack_bf2(p[h * 8 + 2 * e], p[h * 8 + 2 * e + 1]);
+            s.pf[kb][h] = att_bf(w);
+        }
+    }
+    if (rescale) {
+        const float alpha = __builtin_amdgcn_exp2f((s.m_run - m_new) * c_log2);
+        s.l_run *= alpha;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s.ot[d][e] *= alpha;
+        s.m_run = m_new;
+    }
+    s.l_run += psum;
+}
+
+// fragment addresses: K (kb, kk) -> kbase + slot + kk*2048 + kb*512 ; V (d, kb, h) -> vbase + slot + kb*8192 + h*4096 + d*512
+// item i < 16: V^T fragment of P.V (d = i>>2, kb = (i>>1)&1, h = i&1); item 16+j: K fragment of S^T (kb = j>>3, kk = j&7)
+MG_DEV const char* att_frag(const char* smem, int kbase, int vbase, int i, int vslot, int kslot) {
+    if (i < 16) return smem + V_OFF(vslot) + vbase + ((i >> 1) & 1) * 8192 + (i & 1) * 4096 + (i >> 2) * 512;
+    const int j = i - 16;
+    return smem + K_OFF(kslot) + kbase + (j & 7) * 2048 + (j >> 3) * 512;
+}
+
+// byte offset (compile-time) of fragment item i relative to the per-lane base (vbase for i < 16, kbase otherwise)
+constexpr int att_frag_off(int i, int vslot, int kslot) {
+    return i < 16 ? V_OFF(vslot) + ((i >> 1) & 1) * 8192 + (i & 1) * 4096 + (i >> 2) * 512
+                  : K_OFF(kslot) + ((i - 16) & 7) * 2048 + ((i - 16) >> 3) * 512;
+}
+
+// Matrix work, items [I0, I1), with the fragment reads HAND-ISSUED: hipcc guards a ring of plain
+// loads with `s_waitcnt lgkmcnt(0)` every few MFMAs, i.e. it always waits for the read it issued
+// last, with zero cover.  Here ds_read_b128 is inline asm (invisible to hipcc's waitcnt pass), DEPTH
+// reads are kept in flight and MFMA i is preceded by a COUNTED lgkmcnt(min(DEPTH-1, I1-1-i)):
+// LDS returns in order, so that is exactly "fragment i has landed".  sched_barrier(0) pins the
+// builtin MFMAs between the asm statements (cdna guide §5.4 rule 18).  lds_v / lds_k are the
+// per-lane LDS byte addresses (workgroup LDS base + vbase / kbase); VS/KS the tile slots.
+// Compile-time recursion: the asm "i" operands must be constants before unrolling.
+template <int I, int VS, int KS>
+MG_DEV void att_rd(bf16x8_t& dst, unsigned lds_v, unsigned lds_k) {
+    if constexpr (I < 16)
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_v), "i"(att_frag_off(I, VS, KS)));
+    else
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_k), "i"(att_frag_off(I, VS, KS)));
+}
+template <int I, int I0, int I1, int DEPTH, int VS, int KS>
+MG_DEV void att_matrix_step(AttState& s, const bf16x8_t (&qf)[8], bf16x8_t (&f)[DEPTH], unsigned lds_v, unsigned lds_k) {
+    if constexpr (I < I1) {
+        constexpr int r = (I - I0) % DEPTH;
+        constexpr int pending = (I1 - 1 - I) < (DEPTH - 1) ? (I1 - 1 - I) : (DEPTH - 1);  // reads younger than item I
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(pending) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (I < 16) {
+            s.ot[I >> 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[r], s.pf[(I >> 1) & 1][I & 1], s.ot[I >> 2], 0, 0, 0);
+        } else {
+            constexpr int j = I - 16;
+            if constexpr ((j & 7) == 0) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) s.st[j >> 3][e] = 0.f;
+            }
+            s.st[j >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[r], qf[j & 7], s.st[j >> 3], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (I + DEPTH < I1) att_rd<I + DEPTH, VS, KS>(f[r], lds_v, lds_k);
+        att_matrix_step<I + 1, I0, I1, DEPTH, VS, KS>(s, qf, f, lds_v, lds_k);
+    }
+}
+template <int I, int I0, int I1, int DEPTH, int VS, int KS>
+MG_DEV void att_matrix_fill(bf16x8_t (&f)[DEPTH], unsigned lds_v, unsigned lds_k) {
+    if constexpr (I < I0 + DEPTH && I < I1) {
+        att_rd<I, VS, KS>(f[I - I0], lds_v, lds_k);
+        att_matrix_fill<I + 1, I0, I1, DEPTH, VS, KS>(f, lds_v, lds_k);
+    }
+}
+template <int I0, int I1, int DEPTH, int VS, int KS>
+MG_DEV void att_matrix_asm(AttState& s, const bf16x8_t (&qf)[8], unsigned lds_v, unsigned lds_k) {
+    bf16x8_t f[DEPTH];
+    att_matrix_fill<I0, I0, I1, DEPTH, VS, KS>(f, lds_v, lds_k);
+    att_matrix_step<I0, I0, I1, DEPTH, VS, KS>(s, qf, f, lds_v, lds_k);
+}
+
+// matrix work with an explicit DEPTH-deep fragment ring; items [I0, I1) of the list above.
+template <int I0, int I1, int DEPTH>
+MG_DEV void att_matrix(AttState& s, const bf16x8_t (&qf)[8], const char* smem, int kbase, int vbase, int vslot,
+                       int kslot) {
+    bf16x8_t f[DEPTH];
+#pragma unroll
+    for (int i = 0; i < DEPTH; ++i)
+        if (I0 + i < I1) f[i] = *(const bf16x8_t*)att_frag(smem, kbase, vbase, I0 + i, vslot, kslot);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = I0; i < I1; ++i) {
+        const int r = (i - I0) % DEPTH;
+        if (i < 16) {
+            s.ot[i >> 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[r], s.pf[(i >> 1) & 1][i & 1], s.ot[i >> 2], 0, 0, 0);
+        } else {
+            const int j = i - 16;
+            if ((j & 7) == 0) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) s.st[j >> 3][e] = 0.f;
+            }
+            s.st[j >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[r], qf[j & 7], s.st[j >> 3], 0, 0, 0);
+        }
+        if (i + DEPTH < I1) f[r] = *(const bf16x8_t*)att_frag(smem, kbase, vbase, i + DEPTH, vslot, kslot);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <bool LAZY, int VARIANT, int DEPTH, bool ASM>
+__global__ __launch_bounds__(ATT_THREADS, 2) void attn_hd128_kernel(
+    const uint16_t* __restrict__ q, int64_t ldq, const uint16_t* __restrict__ kp, const uint16_t* __restrict__ vp,
+    uint16_t* __restrict__ o, int64_t ldo, int64_t Lq, int64_t Lk, int heads, float c_log2, int nqb) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
+
+    const int bid = blockIdx.x;
+    const int head = bid / nqb;
+    const int qb = bid - head * nqb;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;
+    const int lane = tid & 63, l31 = lane & 31, g = lane >> 5;
+
+    const int64_t qrow_raw = (int64_t)qb * ATT_QB + wave * 32 + l31;
+    const int64_t qrow = qrow_raw < Lq ? qrow_raw : Lq - 1;
+    bf16x8_t qf[8];
+    {
+        const uint16_t* qp = q + qrow * ldq + head * 128 + g * 8;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) qf[kk] = att_bf(*(const u32x4_t*)(qp + kk * 16));
+    }
+
+    const int nkv = (int)((Lk + ATT_KV - 1) / ATT_KV);
+    // LDS-DMA: tile = 16 contiguous KiB; wave w copies pieces 2w, 2w+1 of the K tile and of the V tile
+    const uint16_t* k_src = kp + ((int64_t)head * nkv) * 8192 + wave * 1024 + lane * 8;
+    const uint16_t* v_src = vp + ((int64_t)head * nkv) * 8192 + wave * 1024 + lane * 8;
+    auto dma = [&](int tk, int tv) __attribute__((always_inline)) {
+        if (tk < nkv) {
+            char* dst = smem + K_OFF(tk & 1) + wave * 2048;
+            att_glds16(k_src + (int64_t)tk * 8192, dst);
+            att_glds16(k_src + (int64_t)tk * 8192 + 512, dst + 1024);
+        }
+        if (tv < nkv) {
+            char* dst = smem + V_OFF(tv & 1) + wave * 2048;
+            att_glds16(v_src + (int64_t)tv * 8192, dst);
+            att_glds16(v_src + (int64_t)tv * 8192 + 512, dst + 1024);
+        }
+    };
+
+    const int kperm = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
+    const int kbase = g * 1024 + kperm * 16;
+    const int vbase = g * 2048 + l31 * 16;
+    const unsigned lds0 = (unsigned)(uintptr_t)(att_lptr_t)smem;   // LDS byte address of the workgroup's array
+    const unsigned lds_k = lds0 + kbase, lds_v = lds0 + vbase;
+
+    AttState s;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s.ot[d][e] = 0.f;
+    s.m_run = -1e30f;
+    s.l_run = 0.f;
+
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) asm volatile("" : "+v"(qf[kk]));  // retire the Q loads before any loop
+
+    if (VARIANT == 0) {
+        // ------------------------------ lock-step ------------------------------------------------
+        dma(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        auto tile = [&](int t, auto parity) __attribute__((always_inline)) {
+            constexpr int P = decltype(parity)::value;
+            dma(t + 1, t + 1);                                   // into the other slots, lands under the MFMAs
+            if constexpr (ASM) att_matrix_asm<16, 32, DEPTH, P, P>(s, qf, lds_v, lds_k);
+            else att_matrix<16, 32, DEPTH>(s, qf, smem, kbase, vbase, P, P);   // S^T(t)
+            const int lim = (int)((Lk - (int64_t)t * ATT_KV) < ATT_KV ? (Lk - (int64_t)t * ATT_KV) : ATT_KV);
+            att_softmax<LAZY>(s, lim, g, c_log2);
+            if constexpr (ASM) att_matrix_asm<0, 16, DEPTH, P, P>(s, qf, lds_v, lds_k);
+            else att_matrix<0, 16, DEPTH>(s, qf, smem, kbase, vbase, P, P);    // O^T += V^T(t).P^T
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        };
+        int t = 0;
+        for (; t + 1 < nkv; t += 2) {
+            tile(t, std::integral_constant<int, 0>{});
+            tile(t + 1, std::integral_constant<int, 1>{});
+        }
+        if (t < nkv) tile(t, std::integral_constant<int, 0>{});
+    } else {
+        // ------------------------------ ping-pong ------------------------------------------------
+        // K(0), V(0), K(1) resident; both groups run the same stream, group B one barrier behind.
+        dma(0, 0);
+        dma(1, nkv);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (grp == 1) __syncthreads();
+        if constexpr (ASM) att_matrix_asm<16, 32, DEPTH, 0, 0>(s, qf, lds_v, lds_k);
+        else att_matrix<16, 32, DEPTH>(s, qf, smem, kbase, vbase, 0, 0);       // S^T(0)
+        __syncthreads();
+        auto tile = [&](int t, auto parity) __attribute__((always_inline)) {
+            constexpr int P = decltype(parity)::value;
+            // vector segment: softmax(t).  Interval 2t+1 for group B = where K(t)/V(t-1) slots die.
+            // A refill issued in one segment is only needed two intervals later, so it is retired
+            // (vmcnt(0)) at the END OF THE FOLLOWING segment of the issuing wave — the DMA flies
+            // for a whole matrix segment.  Raw s_barrier: __syncthreads() would drain it at once.
+            if (grp == 1) dma(t + 2, t + 1);
+            const int lim = (int)((Lk - (int64_t)t * ATT_KV) < ATT_KV ? (Lk - (int64_t)t * ATT_KV) : ATT_KV);
+            att_softmax<LAZY>(s, lim, g, c_log2);
+            if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // A's refill from its last matrix segment
+            __builtin_amdgcn_s_barrier();
+            // matrix segment: P.V(t) [V slot P] ; S^T(t+1) [K slot 1-P]
+            if (grp == 0) dma(t + 2, t + 1);
+            // branch-free on purpose: for the last tile the S^T(t+1) half multiplies stale LDS into
+            // registers nobody reads (16 wasted MFMAs per workgroup); a conditional here makes hipcc
+            // merge two definitions of the accumulators and spill ~60 VGPRs.
+            // (s_setprio(2) around this segment was measured: -2..-6 %, not kept)
+            if constexpr (ASM) att_matrix_asm<0, 32, DEPTH, P, 1 - P>(s, qf, lds_v, lds_k);
+            else att_matrix<0, 32, DEPTH>(s, qf, smem, kbase, vbase, P, 1 - P);
+            if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // B's refill from its vector segment
+            __builtin_amdgcn_s_barrier();
+        };
+        int t = 0;
+        for (; t + 1 < nkv; t += 2) {
+            tile(t, std::integral_constant<int, 0>{});
+            tile(t + 1, std::integral_constant<int, 1>{});
+        }
+        if (t < nkv) tile(t, std::integral_constant<int, 0>{});
+        if (grp == 0) __syncthreads();
+    }
+
+    const float l_tot = s.l_run + __shfl_xor(s.l_run, 32, 64);
+    const float inv = 1.f / l_tot;
+    if (qrow_raw < Lq) {
+        uint16_t* op = o + qrow_raw * ldo + head * 128 + g * 4;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                uint2 pk;
+                pk.x = pack_bf2(s.ot[d][rq * 4 + 0] * inv, s.ot[d][rq * 4 + 1] * inv);
+                pk.y = pack_bf2(s.ot[d][rq * 4 + 2] * inv, s.ot[d][rq * 4 + 3] * inv);
+                *(uint2*)(op + d * 32 + rq * 8) = pk;
+            }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// K / V -> packed tiles (see the header of this file)
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_kv_kernel(const uint16_t* __restrict__ k, int64_t ldk,
+                                                      const uint16_t* __restrict__ v, int64_t ldv, int64_t L,
+                                                      uint16_t* __restrict__ kp, uint16_t* __restrict__ vp, int nt) {
+    __shared__ uint16_t tile[64][128 + 8];
+    const int head = blockIdx.y, t = blockIdx.x;
+    const int64_t k0 = (int64_t)t * 64;
+    const int64_t tbase = ((int64_t)head * nt + t) * 8192;
+    if (k) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int id = threadIdx.x + i * 256;      // (r, c): coalesced 256-B row reads
+            const int r = id >> 4, c = id & 15;
+            u16x8_t u = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (k0 + r < L) u = *(const u16x8_t*)(k + (k0 + r) * ldk + head * 128 + c * 8);
+            *(u16x8_t*)(kp + tbase + c * 512 + r * 8) = u;
+        }
+    }
+    if (v) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int id = threadIdx.x + i * 256;
+            const int r = id >> 4, c = id & 15;
+            u16x8_t u = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (k0 + r < L) u = *(const u16x8_t*)(v + (k0 + r) * ldv + head * 128 + c * 8);
+            *(u16x8_t*)&tile[r][c * 8] = u;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int id = threadIdx.x + i * 256;      // (kc, d): 2-KiB contiguous runs per kc
+            const int kc = id >> 7, d = id & 127;
+            u16x8_t u;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) u[j] = tile[kc * 8 + j][d];
+            *(u16x8_t*)(vp + tbase + kc * 1024 + d * 8) = u;
+        }
+    }
+}
+
+extern "C" int mg_pack_kv_bf16(const uint16_t* k, int64_t ldk, const uint16_t* v, int64_t ldv, int64_t L, int heads,
+                               int head_dim, uint16_t* kp, uint16_t* vp, void* stream) {
+    if ((!k && !v) || (k && !kp) || (v && !vp)) return MG_ERR_ARG;
+    if (head_dim != 128 || heads <= 0 || L <= 0 || (k && (ldk & 7)) || (v && (ldv & 7))) return MG_ERR_SHAPE;
+    const int nt = (int)((L + 63) / 64);
+    hipLaunchKernelGGL(pack_kv_kernel, dim3(nt, heads), dim3(256), 0, (hipStream_t)stream, k, ldk, v, ldv, L, kp, vp,
+                       nt);
+    return mg_check_launch();
+}
+
+static int g_attn_lazy = 1;
+static int g_attn_variant = 0;
+extern "C" void mg_attn_set_lazy_rescale(int on) { g_attn_lazy = on; }
+extern "C" void mg_attn_set_variant(int v) { g_attn_variant = v; }
+
+extern "C" int mg_attn_fwd_bf16_hd128(const uint16_t* q, int64_t ldq, const uint16_t* kp, const uint16_t* vp,
+                                      uint16_t* o, int64_t ldo, int64_t Lq, int64_t Lk, int heads, float scale,
+                                      void* stream) {
+    if (!q || !kp || !vp || !o) return MG_ERR_ARG;
+    if (Lq < 0 || Lk <= 0 || heads <= 0) return MG_ERR_SHAPE;
+    if ((ldq & 7) || (ldo & 3)) return MG_ERR_SHAPE;
+    if (((uintptr_t)q & 15) || ((uintptr_t)kp & 15) || ((uintptr_t)vp & 15) || ((uintptr_t)o & 7)) return MG_ERR_SHAPE;
+    if (Lq == 0) return MG_OK;
+    const int64_t nqb64 = (Lq + ATT_QB - 1) / ATT_QB;
+    if (nqb64 * heads > 0x7fffffffLL) return MG_ERR_SHAPE;
+    const int nqb = (int)nqb64;
+    const float c_log2 = scale * 1.4426950408889634f;
+    const dim3 grid((unsigned)(nqb * heads)), block(ATT_THREADS);
+    hipStream_t st = (hipStream_t)stream;
+#define ATT_LAUNCH(LZ, VAR, DP) \
+    hipLaunchKernelGGL((attn_hd128_kernel<LZ, (VAR) & 1, DP, ((VAR) >> 1) != 0>), grid, block, 0, st, q, ldq, kp, vp, o, ldo, Lq, Lk, heads, c_log2, nqb)
+    // variant bit 0: 0 lock-step / 1 ping-pong; bit 1: fragment reads by hipcc (0) or hand-issued asm (1)
+    switch (g_attn_variant & 3) {
+        case 3: if (g_attn_lazy) ATT_LAUNCH(true, 3, 6); else ATT_LAUNCH(false, 3, 6); break;
+        case 2: if (g_attn_lazy) ATT_LAUNCH(true, 2, 4); else ATT_LAUNCH(false, 2, 4); break;
+        case 1: if (g_attn_lazy) ATT_LAUNCH(true, 1, 4); else ATT_LAUNCH(false, 1, 4); break;
+        default: if (g_attn_lazy) ATT_LAUNCH(true, 0, 4); else ATT_LAUNCH(false, 0, 4); break;
+    }
+#undef ATT_LAUNCH
+    return mg_check_launch();
+}

@@ -197,45 +197,6 @@ extern "C" int mg_rmsnorm_rope_bf16(const uint16_t* x, int64_t ldx, uint16_t* ou
 }
 
 // ---------------------------------------------------------------------------------------------
-// V [L][heads*128] -> V^T [heads][128][Lpad]   (keys contiguous: A operand of the P.V MFMA)
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void transpose_v_kernel(const uint16_t* __restrict__ v, int64_t ldv,
-                                                         int64_t L, uint16_t* __restrict__ vt,
-                                                         int64_t Lpad) {
-    __shared__ uint16_t tile[64][128 + 8];
-    const int head = blockIdx.y;
-    const int64_t k0 = (int64_t)blockIdx.x * 64;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int id = threadIdx.x + i * NT;  // 1024 chunks of 8 bf16
-        const int key = id >> 4, ch = id & 15;
-        u16x8_t u = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (k0 + key < L) u = *(const u16x8_t*)(v + (k0 + key) * ldv + head * 128 + ch * 8);
-        *(u16x8_t*)&tile[key][ch * 8] = u;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int id = threadIdx.x + i * NT;
-        const int d = id >> 3, kc = id & 7;
-        u16x8_t u;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) u[j] = tile[kc * 8 + j][d];
-        *(u16x8_t*)(vt + ((int64_t)head * 128 + d) * Lpad + k0 + kc * 8) = u;
-    }
-}
-
-extern "C" int mg_transpose_v_bf16(const uint16_t* v, int64_t ldv, int64_t L, int heads, int head_dim,
-                                   uint16_t* vt, int64_t Lpad, void* stream) {
-    if (!v || !vt) return MG_ERR_ARG;
-    if (head_dim != 128 || heads <= 0 || (Lpad & 63) || Lpad < L || (ldv & 7) || L < 0) return MG_ERR_SHAPE;
-    if (Lpad == 0) return MG_OK;
-    hipLaunchKernelGGL(transpose_v_kernel, dim3((unsigned)(Lpad / 64), heads), dim3(NT), 0,
-                       (hipStream_t)stream, v, ldv, L, vt, Lpad);
-    return mg_check_launch();
-}
-
-// ---------------------------------------------------------------------------------------------
 // sinusoidal_embedding_1d  — model.py:15-25 (fp64 evaluation, fp32 result)
 // ---------------------------------------------------------------------------------------------
 __global__ void sinusoid_kernel(const void* t, int t_dtype, int n, int dim, float* out) {
@@ -467,5 +428,5 @@ extern "C" int mg_lincomb4_f32(float* out, int64_t n, const float* x0, float c0,
     return mg_check_launch();
 }
 
-extern "C" const char* mg_version(void) { return "moviigen_hip 1 gfx950"; }
-extern "C" int mg_abi_version(void) { return 1; }
+extern "C" const char* mg_version(void) { return "moviigen_hip 2 gfx950"; }
+extern "C" int mg_abi_version(void) { return 2; }

@@ -188,24 +188,29 @@ static void test_rmsnorm_rope(int rows, int dim, int hd, int F, int H, int W, in
     report(nm, err, 6e-2);
 }
 
-static void test_transpose(int64_t L, int heads) {
-    const int64_t Lpad = (L + 63) / 64 * 64;
+static void test_pack(int64_t L, int heads) {
+    const int64_t nt = (L + 63) / 64;
     const int ldv = heads * 128 * 3;  // strided like a fused QKV buffer
-    auto v = randbf((size_t)L * ldv);
-    Dev<uint16_t> dv(v), dvt((size_t)heads * 128 * Lpad);
-    CK(hipMemset(dvt.p, 0xff, dvt.n * 2));
-    int rc = mg_transpose_v_bf16(dv.p + 2 * heads * 128, ldv, L, heads, 128, dvt.p, Lpad, 0);
+    auto kv = randbf((size_t)L * ldv);
+    Dev<uint16_t> dkv(kv), dkp((size_t)heads * nt * 8192), dvp((size_t)heads * nt * 8192);
+    CK(hipMemset(dkp.p, 0xff, dkp.n * 2));
+    CK(hipMemset(dvp.p, 0xff, dvp.n * 2));
+    int rc = mg_pack_kv_bf16(dkv.p + heads * 128, ldv, dkv.p + 2 * heads * 128, ldv, L, heads, 128, dkp.p, dvp.p, 0);
     CK(hipDeviceSynchronize());
-    auto got = dvt.host();
+    auto gk = dkp.host(), gv = dvp.host();
     double err = rc ? 1e9 : 0;
     for (int h = 0; h < heads; ++h)
-        for (int d = 0; d < 128; ++d)
-            for (int64_t kx = 0; kx < Lpad; ++kx) {
-                float ref = kx < L ? bf2f(v[(size_t)kx * ldv + 2 * heads * 128 + h * 128 + d]) : 0.f;
-                err = fmax(err, fabs(bf2f(got[((size_t)h * 128 + d) * Lpad + kx]) - ref));
+        for (int64_t key = 0; key < nt * 64; ++key)
+            for (int d = 0; d < 128; ++d) {
+                const int64_t t = key / 64, r = key % 64;
+                const float rk = key < L ? bf2f(kv[(size_t)key * ldv + heads * 128 + h * 128 + d]) : 0.f;
+                const float rv = key < L ? bf2f(kv[(size_t)key * ldv + 2 * heads * 128 + h * 128 + d]) : 0.f;
+                const size_t tb = ((size_t)h * nt + t) * 8192;
+                err = fmax(err, fabs(bf2f(gk[tb + (d / 8) * 512 + r * 8 + (d % 8)]) - rk));
+                err = fmax(err, fabs(bf2f(gv[tb + (r / 8) * 1024 + d * 8 + (r % 8)]) - rv));
             }
     char nm[128];
-    snprintf(nm, sizeof nm, "transpose_v L%lld heads%d", (long long)L, heads);
+    snprintf(nm, sizeof nm, "pack_kv L%lld heads%d", (long long)L, heads);
     report(nm, err, 0.0);
 }
 
@@ -260,17 +265,17 @@ static void test_gemm(int64_t M, int N, int K, int epi, int nsamp, bool timeit) 
 
 static void test_attn(int64_t Lq, int64_t Lk, int heads, int nsamp, bool timeit, int lazy) {
     const int64_t ld = (int64_t)heads * 128;
-    const int64_t Lpad = (Lk + 63) / 64 * 64;
+    const int64_t npk = (int64_t)heads * ((Lk + 63) / 64) * 8192;
     auto q = randbf((size_t)Lq * ld, 2.0f), k = randbf((size_t)Lk * ld, 2.0f), v = randbf((size_t)Lk * ld);
     // make the softmax peaky for some rows: a few keys aligned with queries
     for (int i = 0; i < 8 && i < Lk && i < Lq; ++i)
         for (int d = 0; d < 128; ++d) k[(size_t)((i * 37) % Lk) * ld + d] = f2bf(3.f * bf2f(q[(size_t)i * ld + d]));
-    Dev<uint16_t> dq(q), dk(k), dv(v), dvt((size_t)heads * 128 * Lpad), dout((size_t)Lq * ld);
+    Dev<uint16_t> dq(q), dk(k), dv(v), dkp((size_t)npk), dvp((size_t)npk), dout((size_t)Lq * ld);
     CK(hipMemset(dout.p, 0xff, dout.n * 2));
     mg_attn_set_lazy_rescale(lazy);
-    int rc = mg_transpose_v_bf16(dv.p, ld, Lk, heads, 128, dvt.p, Lpad, 0);
+    int rc = mg_pack_kv_bf16(dk.p, ld, dv.p, ld, Lk, heads, 128, dkp.p, dvp.p, 0);
     const float scale = 1.f / sqrtf(128.f);
-    rc |= mg_attn_fwd_bf16_hd128(dq.p, ld, dk.p, ld, dvt.p, Lpad, dout.p, ld, Lq, Lk, heads, scale, 0);
+    rc |= mg_attn_fwd_bf16_hd128(dq.p, ld, dkp.p, dvp.p, dout.p, ld, Lq, Lk, heads, scale, 0);
     CK(hipDeviceSynchronize());
     auto got = dout.host();
     double err = rc ? 1e9 : 0;
@@ -306,10 +311,10 @@ static void test_attn(int64_t Lq, int64_t Lk, int heads, int nsamp, bool timeit,
     snprintf(nm, sizeof nm, "attn_fwd Lq%lld Lk%lld heads%d lazy%d", (long long)Lq, (long long)Lk, heads, lazy);
     report(nm, err, 2e-2);
     if (timeit) {
-        float ms = time_ms([&] { mg_attn_fwd_bf16_hd128(dq.p, ld, dk.p, ld, dvt.p, Lpad, dout.p, ld, Lq, Lk, heads, scale, 0); }, 3);
+        float ms = time_ms([&] { mg_attn_fwd_bf16_hd128(dq.p, ld, dkp.p, dvp.p, dout.p, ld, Lq, Lk, heads, scale, 0); }, 3);
         printf("    time %.3f ms  -> %.1f TFLOP/s\n", ms, 4.0 * Lq * Lk * 128 * heads / (ms * 1e-3) / 1e12);
-        float mt = time_ms([&] { mg_transpose_v_bf16(dv.p, ld, Lk, heads, 128, dvt.p, Lpad, 0); }, 3);
-        printf("    transpose_v %.3f ms\n", mt);
+        float mt = time_ms([&] { mg_pack_kv_bf16(dk.p, ld, dv.p, ld, Lk, heads, 128, dkp.p, dvp.p, 0); }, 3);
+        printf("    pack_kv %.3f ms\n", mt);
     }
 }
 
@@ -437,7 +442,7 @@ int main(int argc, char** argv) {
     CK(hipGetDeviceProperties(&prop, 0));
     printf("device: %s  CUs=%d  %s  abi=%d\n", prop.name, prop.multiProcessorCount, mg_version(), mg_abi_version());
     if (argc > 1 && !strcmp(argv[1], "attn")) {  // quick perf loop on the dominant kernel
-        for (int variant = 0; variant < 2; ++variant) {
+        for (int variant = 0; variant < 4; ++variant) {
             printf("== attention variant %d ==\n", variant);
             mg_attn_set_variant(variant);
             test_attn(300, 300, 2, 0, false, 1);
@@ -487,8 +492,8 @@ int main(int argc, char** argv) {
     test_rmsnorm_rope(25, 5120, 128, 2, 5, 5, 25, true);  // SP rank slice
     test_rmsnorm_rope(17, 128, 32, 1, 4, 4, 0, true);
     test_rmsnorm_rope(33, 5120, 128, 1, 1, 1, 0, false);
-    test_transpose(300, 2);
-    test_transpose(64, 1);
+    test_pack(300, 2);
+    test_pack(64, 1);
 
     for (int epi = 0; epi < 4; ++epi) test_gemm(300, 256, 128, epi, 0, false);
     test_gemm(128, 128, 64, 0, 0, false);

@@ -17,10 +17,9 @@ SIGNATURES = {
     'mg_ln_modulate': [c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_int, c_f32, c_int, c_vp, c_int, c_i64, c_vp],
     'mg_rmsnorm_rope_bf16': [c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_vp, c_f32, c_int, c_vp, c_int, c_int,
                              c_int, c_i64, c_vp],
-    'mg_transpose_v_bf16': [c_vp, c_i64, c_i64, c_int, c_int, c_vp, c_i64, c_vp],
+    'mg_pack_kv_bf16': [c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_int, c_vp, c_vp, c_vp],
     'mg_gemm_bf16': [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_vp],
-    'mg_attn_fwd_bf16_hd128': [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_int, c_f32,
-                               c_vp],
+    'mg_attn_fwd_bf16_hd128': [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_f32, c_vp],
     'mg_attn_fwd_bf16_generic': [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_int, c_int,
                                  c_f32, c_vp],
     'mg_attn_set_lazy_rescale': [c_int],
@@ -49,6 +48,7 @@ ERRORS = {-1: 'MG_ERR_ARG (null pointer / bad enum)', -2: 'MG_ERR_SHAPE (unsuppo
           -3: 'MG_ERR_LAUNCH (kernel launch failed)'}
 
 _lib = None
+DEFAULT_ATTN_VARIANT = 0   # must match g_attn_variant in csrc/attn_hd128.hip
 
 
 class MoviigenHipError(RuntimeError):

@@ -47,11 +47,22 @@ def rmsnorm_rope(x, weight, eps, head_dim, out, rope_cs=None, grid=(1, 1, 1), po
     return out
 
 
-def transpose_v(v, heads, head_dim, vt):
-    """v [L, heads*head_dim] bf16 (strided ok) -> vt [heads, head_dim, Lpad] bf16 (zero padded)."""
-    _chk(v, torch.bfloat16, 'v'); _chk(vt, torch.bfloat16, 'vt')
-    lib.call('mg_transpose_v_bf16', _p(v), v.stride(0), v.shape[0], heads, head_dim, _p(vt), vt.shape[2], _st())
-    return vt
+def packed_kv_numel(L, heads):
+    """elements of one packed K (or V) buffer for L keys: heads * ceil(L/64) tiles of 8192."""
+    return heads * ((L + 63) // 64) * 8192
+
+
+def pack_kv(k, v, heads, kp, vp):
+    """k, v [L, heads*128] bf16 (strided column slices ok; either may be None) -> packed 64-key tiles
+    kp / vp (flat bf16 buffers of packed_kv_numel elements) for attention_hd128."""
+    _chk(k, torch.bfloat16, 'k'); _chk(v, torch.bfloat16, 'v'); _chk(kp, torch.bfloat16, 'kp'); _chk(vp, torch.bfloat16, 'vp')
+    ref = k if k is not None else v
+    L = ref.shape[0]
+    for name, buf in (('kp', kp if k is not None else None), ('vp', vp if v is not None else None)):
+        if buf is not None and buf.numel() < packed_kv_numel(L, heads):
+            raise lib.MoviigenHipError(f'{name} too small for {L} keys x {heads} heads')
+    lib.call('mg_pack_kv_bf16', _p(k), 0 if k is None else k.stride(0), _p(v), 0 if v is None else v.stride(0), L,
+             int(heads), 128, _p(kp), _p(vp), _st())
 
 
 def gemm(a, w, bias, epilogue, out, gate=None):
@@ -69,11 +80,14 @@ def gemm(a, w, bias, epilogue, out, gate=None):
     return out
 
 
-def attention_hd128(q, k, vt, out, lk, heads, scale):
-    _chk(q, torch.bfloat16, 'q'); _chk(k, torch.bfloat16, 'k'); _chk(vt, torch.bfloat16, 'vt')
+def attention_hd128(q, kp, vp, out, lk, heads, scale):
+    """q [Lq, >=heads*128] bf16; kp/vp from pack_kv for the same lk keys; out [Lq, >=heads*128]."""
+    _chk(q, torch.bfloat16, 'q'); _chk(kp, torch.bfloat16, 'kp'); _chk(vp, torch.bfloat16, 'vp')
     _chk(out, torch.bfloat16, 'out')
-    lib.call('mg_attn_fwd_bf16_hd128', _p(q), q.stride(0), _p(k), k.stride(0), _p(vt), vt.shape[2], _p(out),
-             out.stride(0), q.shape[0], int(lk), int(heads), float(scale), _st())
+    if min(kp.numel(), vp.numel()) < packed_kv_numel(int(lk), int(heads)):
+        raise lib.MoviigenHipError('packed K/V buffers too small for lk keys')
+    lib.call('mg_attn_fwd_bf16_hd128', _p(q), q.stride(0), _p(kp), _p(vp), _p(out), out.stride(0), q.shape[0],
+             int(lk), int(heads), float(scale), _st())
     return out
 
 

@@ -37,9 +37,11 @@ def flash_attention(q, k, v, q_lens=None, k_lens=None, dropout_p=0., softmax_sca
         vi = v[i, :kl].to(torch.bfloat16).reshape(kl, n * c).contiguous()
         oi = torch.empty(ql, n * c, dtype=torch.bfloat16, device=q.device)
         if c == 128:
-            vt = torch.empty(n, 128, (kl + 63) // 64 * 64, dtype=torch.bfloat16, device=q.device)
-            ops.transpose_v(vi, n, 128, vt)
-            ops.attention_hd128(qi, ki, vt, oi, kl, n, scale)
+            n_pk = ops.packed_kv_numel(kl, n)
+            kp = torch.empty(n_pk, dtype=torch.bfloat16, device=q.device)
+            vp = torch.empty(n_pk, dtype=torch.bfloat16, device=q.device)
+            ops.pack_kv(ki, vi, n, kp, vp)
+            ops.attention_hd128(qi, kp, vp, oi, kl, n, scale)
         else:
             ops.attention_generic(qi, ki, vi, oi, kl, n, c, scale)
         out[i, :ql] = oi.view(ql, n, c)

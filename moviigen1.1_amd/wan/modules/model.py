@@ -8,7 +8,7 @@ reference checkpoint layout: config.json + diffusion_pytorch_model*.safetensors)
 What differs is HOW a forward runs.  The reference composes ~40 torch ops per block under
 autocast; here a block is 14 kernel launches from libmoviigen_hip.so:
 
-    ln_modulate -> gemm(QKV fused, N=3*dim) -> rmsnorm_rope(q) / rmsnorm_rope(k) / transpose_v
+    ln_modulate -> gemm(QKV fused, N=3*dim) -> rmsnorm_rope(q) / rmsnorm_rope(k) / pack_kv
     -> attention -> gemm(o) with `x += y*gate` fused  -> ln_modulate(norm3 affine) -> gemm(q)
     -> rmsnorm -> attention(512 cached text keys) -> gemm(o) with `x += y` fused
     -> ln_modulate -> gemm(ffn.0)+GELU fused -> gemm(ffn.2) with `x += y*gate` fused
@@ -262,15 +262,15 @@ class WanModel(nn.Module):
             bf, f32 = torch.bfloat16, torch.float32
             hd = d // self.num_heads
             Ltot = L * self.sp_size
-            Lpad = (Ltot + 63) // 64 * 64
             e = lambda *s, dt=bf: torch.empty(*s, dtype=dt, device=dev)  # noqa: E731
             ws = dict(x=e(L, d, dt=f32), h=e(L, d), qkv=e(L, 3 * d), q=e(L, d), k=e(L, d), a=e(L, d),
                       u=e(L, f), tok=e(L, self.in_dim * math.prod(self.patch_size)),
                       hf=e(L, d, dt=f32), y=e(L, math.prod(self.patch_size) * self.out_dim, dt=f32),
                       sin=e(1, self.freq_dim, dt=f32), e1=e(d, dt=f32), e=e(d, dt=f32), e0=e(6, d, dt=f32),
                       mod=e(6 * self.num_layers, d, dt=f32), hmod=e(2, d, dt=f32))
-            if hd == 128:
-                ws['vt'] = e(self.num_heads // self.sp_size, 128, Lpad)
+            if hd == 128:   # K / V packed into 64-key tiles (operand layout of the MFMA attention kernel)
+                n_pk = ops.packed_kv_numel(Ltot, self.num_heads // self.sp_size)
+                ws['kp'], ws['vp'] = e(n_pk), e(n_pk)
             if self.sp_size > 1:
                 n_loc = self.num_heads // self.sp_size
                 ws['qg'], ws['kg'], ws['vg'] = e(Ltot, n_loc * hd), e(Ltot, n_loc * hd), e(Ltot, n_loc * hd)
@@ -306,31 +306,32 @@ class WanModel(nn.Module):
         ops.gemm(t0, te['2'].weight, te['2'].bias, ops.BIAS_BF16, emb)
         kv = torch.empty(Lc, 2 * d, dtype=bf, device=dev)
         layers = []
-        Lcpad = (Lc + 63) // 64 * 64
         for li, b in enumerate(self.blocks):
             lw = self._layer(li)
             ops.gemm(emb, lw['wkv_c'], lw['bkv_c'], ops.BIAS_BF16, kv)
             kc = torch.empty(Lc, d, dtype=bf, device=dev)
             ops.rmsnorm_rope(kv[:, :d], b.cross_attn.norm_k.weight, self.eps, hd, kc)
             if hd == 128:
-                vc = torch.empty(self.num_heads, 128, Lcpad, dtype=bf, device=dev)
-                ops.transpose_v(kv[:, d:], self.num_heads, 128, vc)
+                n_pk = ops.packed_kv_numel(Lc, self.num_heads)
+                kcp, vcp = torch.empty(n_pk, dtype=bf, device=dev), torch.empty(n_pk, dtype=bf, device=dev)
+                ops.pack_kv(kc, kv[:, d:], self.num_heads, kcp, vcp)
+                layers.append((kcp, vcp))
             else:
-                vc = kv[:, d:].clone()
-            layers.append((kc, vc))
+                layers.append((kc, kv[:, d:].clone()))
         if len(self._ctx_cache) >= 4:
             self._ctx_cache.pop(next(iter(self._ctx_cache)))
         self._ctx_cache[key] = (ctx, layers)  # keep ctx alive so data_ptr stays unique
         return self._ctx_cache[key]
 
     # ------------------------------------------------------------------------------------------
-    def _attention(self, q, k, v_or_vt, out, lk, heads):
+    def _attention(self, q, k, v, out, lk, heads):
+        """head_dim 128: k, v are PACKED tile buffers (ops.pack_kv); otherwise row-major."""
         hd = self.dim // self.num_heads
         scale = 1.0 / math.sqrt(hd)
         if hd == 128:
-            ops.attention_hd128(q, k, v_or_vt, out, lk, heads, scale)
+            ops.attention_hd128(q, k, v, out, lk, heads, scale)
         else:
-            ops.attention_generic(q, k, v_or_vt, out, lk, heads, hd, scale)
+            ops.attention_generic(q, k, v, out, lk, heads, hd, scale)
 
     def _self_attention(self, ws, blk, grid, rope, L, pos0):
         """model.py:127-156 (and the Ulysses variant xdit_context_parallel.py:155-198)."""
@@ -341,8 +342,8 @@ class WanModel(nn.Module):
         ops.rmsnorm_rope(qkv[:, d:2 * d], sa.norm_k.weight, self.eps, hd, ws['k'], rope, grid, pos0)
         if self.sp_size == 1:
             if hd == 128:
-                ops.transpose_v(qkv[:, 2 * d:], N, 128, ws['vt'])
-                self._attention(ws['q'], ws['k'], ws['vt'], ws['a'], self._kv_valid, N)
+                ops.pack_kv(ws['k'], qkv[:, 2 * d:], N, ws['kp'], ws['vp'])
+                self._attention(ws['q'], ws['kp'], ws['vp'], ws['a'], self._kv_valid, N)
             else:
                 self._attention(ws['q'], ws['k'], qkv[:, 2 * d:], ws['a'], self._kv_valid, N)
             return
@@ -353,8 +354,8 @@ class WanModel(nn.Module):
         ulysses.seq_to_head(qkv[:, 2 * d:], ws['vg'], self.sp_group, self.sp_size, N, hd)
         Ltot = L * self.sp_size
         if hd == 128:
-            ops.transpose_v(ws['vg'], n_loc, 128, ws['vt'])
-            self._attention(ws['qg'], ws['kg'], ws['vt'], ws['ag'], Ltot, n_loc)
+            ops.pack_kv(ws['kg'], ws['vg'], n_loc, ws['kp'], ws['vp'])
+            self._attention(ws['qg'], ws['kp'], ws['vp'], ws['ag'], Ltot, n_loc)
         else:
             self._attention(ws['qg'], ws['kg'], ws['vg'], ws['ag'], Ltot, n_loc)
         ulysses.head_to_seq(ws['ag'], ws['a'], self.sp_group, self.sp_size, N, hd)

@@ -135,7 +135,7 @@ def test_gemm_rejects_bad_shapes(dev):
 
 @pytest.mark.parametrize('Lq,Lk,heads,hd', [(300, 300, 2, 128), (700, 512, 3, 128), (64, 64, 1, 128), (1000, 77, 1, 128),
                                              (16, 16, 4, 32), (50, 37, 2, 64), (1, 1, 1, 128)])
-def test_attention_vs_oracle(dev, Lq, Lk, heads, hd):
+def test_attention_vs_oracle(dev, Lq, Lk, heads, hd, attn_variant):
     from oracle import dit
     from wan.modules.attention import flash_attention
     q = (W.randn((1, Lq, heads, hd), 11) * 1.5).bfloat16()
@@ -154,7 +154,7 @@ def test_attention_vs_oracle(dev, Lq, Lk, heads, hd):
         assert scale_err(out2[0], ref2) < 2e-2
 
 
-def test_attention_rescale_branch(dev):
+def test_attention_rescale_branch(dev, attn_variant):
     """force the online-softmax rescale (a key tile whose scores dwarf the earlier ones) and check
     lazy (defer-max) == eager rescaling (cdna guide §5.4 rule 26)."""
     from oracle import dit
@@ -174,6 +174,15 @@ def test_attention_rescale_branch(dev):
         assert scale_err(outs[-1], ref) < 2e-2, lazy
     lib.load().mg_attn_set_lazy_rescale(1)
     assert scale_err(outs[0], outs[1]) < 2e-2
+
+
+@pytest.fixture(params=[0, 1, 2, 3], ids=['lockstep', 'pingpong', 'lockstep_asm', 'pingpong_asm'])
+def attn_variant(request):
+    """run a test under both schedules of mg_attn_fwd_bf16_hd128."""
+    from wan.backend import lib
+    lib.load().mg_attn_set_variant(request.param)
+    yield request.param
+    lib.load().mg_attn_set_variant(lib.DEFAULT_ATTN_VARIANT)
 
 
 def test_small_fp32_kernels(dev):
@@ -348,38 +357,44 @@ def test_pipeline_cfg1(dev, golden, solver):
 # ------------------------------------------------------------------------------------------------
 # size-independent properties at BASELINE.json configs[1] sizes (L = 75 600, 40 heads, d = 5120)
 # ------------------------------------------------------------------------------------------------
-def test_fullsize_attention_properties(dev):
-    from wan.backend import ops
+@pytest.mark.parametrize('variant', [0, 1, 2, 3])
+def test_fullsize_attention_properties(dev, variant):
+    """both schedules (lock-step, ping-pong) of the MFMA attention kernel at the full 720p size."""
+    from wan.backend import lib, ops
     L, N = 75600, 40
     gen = torch.Generator(device=dev).manual_seed(0)
     q = torch.randn(L, N * 128, device=dev, generator=gen).bfloat16()
     k = torch.randn(L, N * 128, device=dev, generator=gen).bfloat16()
     v = torch.randn(L, N * 128, device=dev, generator=gen).bfloat16()
-    Lpad = (L + 63) // 64 * 64
-    vt = torch.empty(N, 128, Lpad, dtype=torch.bfloat16, device=dev)
+    n_pk = ops.packed_kv_numel(L, N)
+    kpk = torch.empty(n_pk, dtype=torch.bfloat16, device=dev)
+    vpk = torch.empty(n_pk, dtype=torch.bfloat16, device=dev)
     o = torch.empty(L, N * 128, dtype=torch.bfloat16, device=dev)
     sc = 1 / math.sqrt(128)
-    # (1) rows of softmax sum to one: V = const  =>  O = const, for EVERY query and head
-    ones = torch.full_like(v, 0.5)
-    ops.transpose_v(ones, N, 128, vt)
-    ops.attention_hd128(q, k, vt, o, L, N, sc)
-    assert (o.float() - 0.5).abs().max().item() < 4e-3
-    # (2) permuting the keys (and values with them) does not change the output
-    ops.transpose_v(v, N, 128, vt)
-    ops.attention_hd128(q, k, vt, o, L, N, sc)
-    o1 = o.clone()
-    perm = torch.randperm(L, device=dev, generator=gen)
-    kp, vp = k[perm].contiguous(), v[perm].contiguous()
-    ops.transpose_v(vp, N, 128, vt)
-    ops.attention_hd128(q, kp, vt, o, L, N, sc)
-    assert (o.float() - o1.float()).abs().max().item() < 1e-2
-    # (3) a sampled set of rows against fp32 SDPA-by-hand on the GPU-resident data
-    rows = torch.tensor([0, 1, 255, 256, 40000, 75599], device=dev)
-    for h in (0, 17, 39):
-        qs = q[rows, h * 128:(h + 1) * 128].float()
-        s = (qs @ kp[:, h * 128:(h + 1) * 128].float().T) * sc
-        ref = torch.softmax(s, -1) @ vp[:, h * 128:(h + 1) * 128].float()
-        assert (o[rows, h * 128:(h + 1) * 128].float() - ref).abs().max().item() < 5e-3
+    lib.load().mg_attn_set_variant(variant)
+    try:
+        # (1) rows of softmax sum to one: V = const  =>  O = const, for EVERY query and head
+        ops.pack_kv(k, torch.full_like(v, 0.5), N, kpk, vpk)
+        ops.attention_hd128(q, kpk, vpk, o, L, N, sc)
+        assert (o.float() - 0.5).abs().max().item() < 4e-3
+        # (2) permuting the keys (and values with them) does not change the output
+        ops.pack_kv(k, v, N, kpk, vpk)
+        ops.attention_hd128(q, kpk, vpk, o, L, N, sc)
+        o1 = o.clone()
+        perm = torch.randperm(L, device=dev, generator=gen)
+        kp, vp = k[perm].contiguous(), v[perm].contiguous()
+        ops.pack_kv(kp, vp, N, kpk, vpk)
+        ops.attention_hd128(q, kpk, vpk, o, L, N, sc)
+        assert (o.float() - o1.float()).abs().max().item() < 1e-2
+        # (3) a sampled set of rows against fp32 SDPA-by-hand on the GPU-resident data
+        rows = torch.tensor([0, 1, 255, 256, 40000, 75599], device=dev)
+        for h in (0, 17, 39):
+            qs = q[rows, h * 128:(h + 1) * 128].float()
+            s = (qs @ kp[:, h * 128:(h + 1) * 128].float().T) * sc
+            ref = torch.softmax(s, -1) @ vp[:, h * 128:(h + 1) * 128].float()
+            assert (o[rows, h * 128:(h + 1) * 128].float() - ref).abs().max().item() < 5e-3
+    finally:
+        lib.load().mg_attn_set_variant(lib.DEFAULT_ATTN_VARIANT)
 
 
 def test_fullsize_gemm_properties(dev):
