@@ -171,6 +171,27 @@ int mg_cfg_combine_f32(float* out, const float* uncond, const float* cond, float
                        int64_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * umT5 text encoder glue (the GEMMs are mg_gemm_bf16, the T5LayerNorm is
+ * mg_rmsnorm_rope_bf16 without RoPE).  Reference wan/modules/t5.py, model in bf16.
+ * ---------------------------------------------------------------------------------------- */
+
+/* token_embedding lookup, t5.py:273,289: out[i][:] = table[clamp(ids[i])][:]; dim % 8 == 0. */
+int mg_embed_rows_bf16(const uint16_t* table, int64_t vocab, int dim, const int64_t* ids, int n,
+                       uint16_t* out, void* stream);
+
+/* bf16 elementwise, n % 8 == 0: mode 0 out = a + b (residual add of bf16 tensors, t5.py:165-166);
+ * mode 1 out = a * gelu_tanh(b) (T5FeedForward fc1(x) * gate(x), t5.py:40-44,135). */
+int mg_ew_bf16(const uint16_t* a, const uint16_t* b, uint16_t* out, int64_t n, int mode, void* stream);
+
+/* T5Attention, t5.py:82-113: softmax(q k^T + emb[bucket(j-i)][head]) v, NO 1/sqrt(d) scaling,
+ * keys >= Lk masked.  q,k,v [L][heads*head_dim] (row stride ld), rel_emb [num_buckets][heads] bf16,
+ * rel_bucket[(j - i) + Lq - 1] (int32, Lq + Lk - 1 entries) = T5RelativeEmbedding bucket of the
+ * relative position (t5.py:242-263), tabulated by the host.  head_dim <= 128. */
+int mg_t5_attn_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v, int64_t ld,
+                    const uint16_t* rel_emb, const int* rel_bucket, uint16_t* o, int64_t ldo,
+                    int64_t Lq, int64_t Lk, int heads, int head_dim, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * WanVAE decode (fp32, channels-last activations [T][H][W][C])
  * ---------------------------------------------------------------------------------------- */
 

@@ -33,6 +33,9 @@ SIGNATURES = {
     'mg_unpatchify_f32': [c_vp, c_i64, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp],
     'mg_lincomb4_f32': [c_vp, c_i64, c_vp, c_f32, c_vp, c_f32, c_vp, c_f32, c_vp, c_f32, c_vp],
     'mg_cfg_combine_f32': [c_vp, c_vp, c_vp, c_f32, c_i64, c_vp],
+    'mg_embed_rows_bf16': [c_vp, c_i64, c_int, c_vp, c_int, c_vp, c_vp],
+    'mg_ew_bf16': [c_vp, c_vp, c_vp, c_i64, c_int, c_vp],
+    'mg_t5_attn_bf16': [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_vp],
     'mg_vae_conv_f32': [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int,
                         c_int, c_vp, c_vp, c_vp],
     'mg_vae_rmsnorm_silu_f32': [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp],

@@ -156,6 +156,36 @@ def cfg_combine(out, uncond, cond, g):
     return out
 
 
+# ---- umT5 encoder glue ---------------------------------------------------------------------------
+def embed_rows(table, ids, out):
+    _chk(table, torch.bfloat16, 'table'); _chk(ids, torch.int64, 'ids'); _chk(out, torch.bfloat16, 'out')
+    lib.call('mg_embed_rows_bf16', _p(table), table.shape[0], table.shape[1], _p(ids), ids.numel(), _p(out), _st())
+    return out
+
+
+def ew_bf16(a, b, out, mode):
+    """mode 0: a + b; mode 1: a * gelu_tanh(b) — contiguous bf16 tensors of equal size."""
+    for n, t in (('a', a), ('b', b), ('out', out)):
+        _chk(t, torch.bfloat16, n)
+        if not t.is_contiguous():
+            raise lib.MoviigenHipError(f'{n} must be contiguous')
+    lib.call('mg_ew_bf16', _p(a), _p(b), _p(out), out.numel(), int(mode), _st())
+    return out
+
+
+def t5_attention(q, k, v, rel_emb, rel_bucket, out, lk, heads, head_dim):
+    """q, k, v: column slices of one [L, 3*heads*head_dim] buffer (same row stride)."""
+    _chk(q, torch.bfloat16, 'q'); _chk(k, torch.bfloat16, 'k'); _chk(v, torch.bfloat16, 'v')
+    _chk(rel_emb, torch.bfloat16, 'rel_emb'); _chk(rel_bucket, torch.int32, 'rel_bucket'); _chk(out, torch.bfloat16, 'out')
+    if not (q.stride(0) == k.stride(0) == v.stride(0)):
+        raise lib.MoviigenHipError('q, k, v must share a row stride')
+    if rel_bucket.numel() != q.shape[0] + int(lk) - 1:
+        raise lib.MoviigenHipError('rel_bucket must have Lq + Lk - 1 entries')
+    lib.call('mg_t5_attn_bf16', _p(q), _p(k), _p(v), q.stride(0), _p(rel_emb), _p(rel_bucket), _p(out), out.stride(0),
+             q.shape[0], int(lk), int(heads), int(head_dim), _st())
+    return out
+
+
 # ---- VAE (fp32, channels-last) -------------------------------------------------------------------
 def vae_conv(x, w, bias, out, kt, kh, kw, cache=None, up2=False, residual=None):
     """x [T,H,W,Cin]; w [Cout,kt,kh,kw,Cin]; out [T,Ho,Wo,Cout]."""

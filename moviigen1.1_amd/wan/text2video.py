@@ -5,10 +5,10 @@ Same constructor and `generate()` signature, defaults and return contract
 the MI355X engine: WanModel (HIP kernels), the fused-update schedulers, WanVAE (HIP kernels),
 Ulysses over RCCL when `use_usp`, block-sharded weights when `dit_fsdp`.
 
-The umT5-XXL text encoder is the step BEFORE the hot path: its output
-`[<=512, 4096]` is an input of this pipeline.  `input_prompt` / `n_prompt` may therefore also be
-pre-computed embedding tensors; strings need a `text_encoder` callable (prompt list, device) ->
-list of tensors, exactly the reference's T5EncoderModel.__call__ contract.
+The umT5-XXL text encoder (wan/modules/t5.py on the same HIP kernels) is
+created from `checkpoint_dir/config.t5_checkpoint` as in the reference when that file exists;
+`text_encoder=` injects any callable with T5EncoderModel's contract (prompt list, device) -> list
+of `[len<=512, 4096]` tensors, and `input_prompt` / `n_prompt` may also be pre-computed embeddings.
 """
 import gc
 import logging
@@ -37,6 +37,16 @@ class WanT2V:
         self.t5_cpu = t5_cpu
         self.num_train_timesteps = config.num_train_timesteps
         self.param_dtype = config.param_dtype
+        if t5_fsdp:
+            raise NotImplementedError('t5_fsdp: the 9.4 GB bf16 encoder is replicated (288 GB HBM per GPU)')
+        if t5_cpu:
+            raise NotImplementedError('t5_cpu: the text encoder has no CPU path in this build')
+        t5_path = os.path.join(checkpoint_dir, config.t5_checkpoint) if checkpoint_dir else None
+        if text_encoder is None and t5_path and os.path.exists(t5_path):
+            from .modules.t5 import T5EncoderModel
+            text_encoder = T5EncoderModel(text_len=config.text_len, dtype=config.t5_dtype, device=self.device,
+                                          checkpoint_path=t5_path,
+                                          tokenizer_path=os.path.join(checkpoint_dir, config.t5_tokenizer))
         self.text_encoder = text_encoder
         self.vae_stride = config.vae_stride
         self.patch_size = config.patch_size
@@ -67,11 +77,11 @@ class WanT2V:
         if isinstance(prompt, (list, tuple)) and prompt and torch.is_tensor(prompt[0]):
             return [p.to(self.device) for p in prompt]
         if self.text_encoder is None:
-            raise NotImplementedError(
-                'no text encoder attached: pass pre-computed umT5 embeddings ([len<=512, 4096] tensors) as '
-                '`input_prompt`/`n_prompt`, or construct WanT2V(text_encoder=callable)')
-        dev = torch.device('cpu') if self.t5_cpu else self.device
-        return [t.to(self.device) for t in self.text_encoder([prompt], dev)]
+            raise FileNotFoundError(
+                'no text encoder: config.t5_checkpoint not found in the checkpoint dir; pass pre-computed '
+                'umT5 embeddings ([len<=512, 4096] tensors) as `input_prompt`/`n_prompt`, or '
+                'WanT2V(text_encoder=callable)')
+        return [t.to(self.device) for t in self.text_encoder([prompt], self.device)]
 
     def generate(self, input_prompt, size=(1280, 720), frame_num=81, shift=5.0, sample_solver='unipc',
                  sampling_steps=50, guide_scale=5.0, n_prompt="", seed=-1, offload_model=True,

@@ -129,6 +129,11 @@ def load_ref():
     model = importlib.import_module('wan.modules.model')
     model.flash_attention = sdpa_flash_attention
     vae = importlib.import_module('wan.modules.vae')
+    # t5.py evaluates torch.cuda.current_device() in a default argument and imports ftfy via tokenizers
+    torch.cuda.current_device = lambda: 0
+    sys.modules.setdefault('ftfy', types.ModuleType('ftfy'))
+    global t5ref
+    t5ref = importlib.import_module('wan.modules.t5')
     unipc = importlib.import_module('wan.utils.fm_solvers_unipc')
     dpm = importlib.import_module('wan.utils.fm_solvers')
     return model, vae, unipc, dpm
@@ -312,5 +317,34 @@ def main():
     save('g6_pipeline_cfg1', **arrs)
 
 
+@torch.no_grad()
+def t5_golden():
+    """G7: umT5 encoder (tiny config) in fp32 and in the deployment dtype bf16, two padded prompts."""
+    cfg = W.TINY_T5
+    P = W.make_t5_params(cfg, 2)
+    enc = t5ref.T5Encoder(cfg['vocab_size'], cfg['dim'], cfg['dim_attn'], cfg['dim_ffn'], cfg['num_heads'],
+                          cfg['num_layers'], cfg['num_buckets'], shared_pos=False, dropout=0.0).eval()
+    missing, unexpected = enc.load_state_dict(P, strict=True)
+    rs = np.random.RandomState(3)
+    L = 24
+    ids = torch.from_numpy(rs.randint(1, cfg['vocab_size'], size=(2, L))).long()
+    lens = [17, 24]
+    mask = torch.zeros(2, L, dtype=torch.long)
+    for i, n in enumerate(lens):
+        mask[i, :n] = 1
+        ids[i, n:] = 0
+    out32 = enc(ids, mask)
+    encb = enc.to(torch.bfloat16)
+    outbf = encb(ids, mask).float()
+    save('g7_t5', ids=ids, mask=mask, out_fp32=out32, out_bf16=outbf,
+         buckets=enc.blocks[0].pos_embedding._relative_position_bucket(
+             torch.arange(L).unsqueeze(0) - torch.arange(L).unsqueeze(1)))
+
+
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 't5':
+        load_ref()
+        t5_golden()
+    else:
+        main()
+        t5_golden()

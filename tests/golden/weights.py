@@ -135,3 +135,42 @@ def make_vae_params(dim=8, seed=1, z_dim=16):
 
 def randn(shape, seed):
     return _t(np.random.RandomState(seed).standard_normal(shape))
+
+
+# ---- umT5 encoder ---------------------------------------------------------------
+TINY_T5 = dict(vocab_size=100, dim=128, dim_attn=128, dim_ffn=256, num_heads=4, num_layers=2, num_buckets=32)
+
+
+def t5_param_shapes(cfg):
+    d, da, f = cfg['dim'], cfg['dim_attn'], cfg['dim_ffn']
+    sh = {'token_embedding.weight': (cfg['vocab_size'], d), 'norm.weight': (d,)}
+    for i in range(cfg['num_layers']):
+        p = f'blocks.{i}.'
+        sh[p + 'norm1.weight'] = (d,)
+        sh[p + 'norm2.weight'] = (d,)
+        for n in 'qkv':
+            sh[p + f'attn.{n}.weight'] = (da, d)
+        sh[p + 'attn.o.weight'] = (d, da)
+        sh[p + 'ffn.gate.0.weight'] = (f, d)
+        sh[p + 'ffn.fc1.weight'] = (f, d)
+        sh[p + 'ffn.fc2.weight'] = (d, f)
+        sh[p + 'pos_embedding.embedding.weight'] = (cfg['num_buckets'], cfg['num_heads'])
+    return sh
+
+
+def make_t5_params(cfg, seed=2):
+    rs = np.random.RandomState(seed)
+    P = {}
+    for name, shape in t5_param_shapes(cfg).items():
+        if 'norm' in name:
+            a = 1.0 + 0.1 * rs.standard_normal(shape)
+        elif name == 'token_embedding.weight':
+            a = rs.standard_normal(shape)
+        elif 'pos_embedding' in name:
+            a = 0.5 * rs.standard_normal(shape)
+        elif name.endswith('q.weight'):
+            a = rs.standard_normal(shape) * (shape[1] ** -0.5) * 0.5   # T5 has no 1/sqrt(d): keep logits O(1)
+        else:
+            a = rs.standard_normal(shape) * (shape[1] ** -0.5)
+        P[name] = _t(a)
+    return P

@@ -431,3 +431,101 @@ def test_sequence_parallel_two_ranks_one_gpu():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert 'SP_OK rank0' in r.stdout and 'SP_OK rank1' in r.stdout
     assert 'SP_FSDP_OK rank0' in r.stdout and 'SP_FSDP_OK rank1' in r.stdout
+
+
+# ------------------------------------------------------------------------------------------------
+# umT5 encoder
+# ------------------------------------------------------------------------------------------------
+def _t5_model(dev, cfg=W.TINY_T5, seed=2):
+    from wan.modules.t5 import T5Encoder
+    m = T5Encoder(**{('vocab' if k == 'vocab_size' else k): v for k, v in cfg.items()})
+    m.load_state_dict(W.make_t5_params(cfg, seed))
+    return m.to(dev)
+
+
+def test_t5_kernels_vs_oracle(dev):
+    from oracle import t5 as ot5
+    from wan.backend import ops
+    from wan.modules.t5 import relative_buckets
+    bf = torch.bfloat16
+    # embedding gather + elementwise
+    tab = W.randn((50, 128), 1).to(bf)
+    ids = torch.tensor([3, 49, 0, 7, 7], dtype=torch.int64)
+    out = torch.empty(5, 128, dtype=bf, device=dev)
+    ops.embed_rows(tab.to(dev), ids.to(dev), out)
+    assert torch.equal(out.cpu(), tab[ids])
+    a, b = W.randn((33, 257), 2).to(bf), (W.randn((33, 257), 3) * 2).to(bf)
+    o = torch.empty(33, 257, dtype=bf, device=dev)
+    ops.ew_bf16(a.to(dev), b.to(dev), o, 0)
+    assert torch.equal(o.cpu(), (a.float() + b.float()).to(bf))
+    ops.ew_bf16(a.to(dev), b.to(dev), o, 1)
+    g = b.float()
+    ref = a.float() * (0.5 * g * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (g + 0.044715 * g ** 3))))
+    assert scale_err(o.float(), ref.to(bf).float()) < 1e-2
+    # attention with relative-position bias, no scaling
+    for L, heads, hd in ((17, 4, 32), (24, 4, 32), (200, 2, 64), (1, 2, 64)):
+        qkv = (W.randn((L, 3 * heads * hd), 4) * 0.5).to(bf)
+        emb = (W.randn((32, heads), 5) * 0.5).to(bf)
+        da = heads * hd
+        q, k, v = (qkv[:, i * da:(i + 1) * da].float().view(L, heads, hd).permute(1, 0, 2) for i in range(3))
+        s = (q @ k.transpose(1, 2)).to(bf).float() + ot5.pos_bias(emb.float(), L, L, 32)
+        p = torch.softmax(s.to(bf).float(), -1)
+        ref = (p @ v).permute(1, 0, 2).reshape(L, da)
+        qd = qkv.to(dev)
+        o = torch.empty(L, da, dtype=bf, device=dev)
+        ops.t5_attention(qd[:, :da], qd[:, da:2 * da], qd[:, 2 * da:], emb.to(dev), relative_buckets(L).to(dev), o,
+                         L, heads, hd)
+        assert scale_err(o.float(), ref) < 1.5e-2, (L, heads, hd)
+
+
+def test_t5_encoder_vs_reference(dev, golden):
+    """HIP encoder vs the imported reference (g7): as close to the fp32 truth as the reference's own
+    bf16 run, and within the bf16 tolerance of the bf16-emulating oracle."""
+    from oracle import t5 as ot5
+    g = golden('g7_t5')
+    m = _t5_model(dev)
+    ids, mask = T(g['ids']), T(g['mask'])
+    out = m(ids.to(dev), mask.to(dev)).float().cpu()
+    P = W.make_t5_params(W.TINY_T5, 2)
+    for b in range(ids.shape[0]):
+        kl = int(mask[b].sum())
+        truth, ref_bf = g['out_fp32'][b, :kl], g['out_bf16'][b, :kl].astype(np.float32)
+        got = out[b, :kl]
+        assert rel_l2(got, truth) < 1.25 * rel_l2(T(ref_bf), truth) + 1e-3
+        assert rel_l2(got, ot5.t5_encode(P, W.TINY_T5, ids[b], kl, True)) < 2e-2
+        assert (out[b, kl:] == 0).all()
+    # batch-of-one / no mask, determinism
+    one = m(ids[1:2].to(dev)).float().cpu()
+    assert torch.equal(one[0], out[1])
+
+
+def test_t5_encoder_model_contract(dev):
+    """T5EncoderModel.__call__ contract (reference t5.py:504-518) with an injected tokenizer, at the
+    real width (dim 4096, 64 heads, ffn 10240; 2 layers, small vocab) against the oracle."""
+    from oracle import t5 as ot5
+    from wan.modules.t5 import T5EncoderModel
+    cfg = dict(vocab_size=512, dim=4096, dim_attn=4096, dim_ffn=10240, num_heads=64, num_layers=2, num_buckets=32)
+    m = _t5_model('cpu', cfg, seed=5)
+    text_len = 64
+    rs = np.random.RandomState(7)
+
+    class Tok:
+        def __call__(self, texts, return_mask=False, add_special_tokens=True):
+            ids = torch.zeros(len(texts), text_len, dtype=torch.long)
+            mask = torch.zeros(len(texts), text_len, dtype=torch.long)
+            for i, t in enumerate(texts):
+                n = min(len(t.split()) + 1, text_len)
+                ids[i, :n] = T(rs.randint(1, 512, n))
+                mask[i, :n] = 1
+            self.last = ids, mask
+            return ids, mask
+
+    tok = Tok()
+    enc = T5EncoderModel(text_len, device=dev, model=m, tokenizer=tok)
+    outs = enc(['a b c d e f g h i j k', ' '.join(['w'] * 80)], dev)
+    ids, mask = tok.last
+    assert [tuple(o.shape) for o in outs] == [(12, 4096), (64, 4096)]
+    assert all(o.dtype == torch.bfloat16 and o.device.type == 'cuda' for o in outs)
+    P = W.make_t5_params(cfg, 5)
+    ref = ot5.t5_encode(P, cfg, ids[0], 12, True)
+    assert rel_l2(outs[0].float(), ref) < 2e-2

@@ -155,3 +155,47 @@ def test_pipeline_cfg1(golden):
     x0, _ = schedulers.sample_loop(model_fn, T(g['noise']), T(g['ctx']), T(g['ctx_null']), 2, 5.0, 5.0, 'unipc')
     video = vae.vae_decode(W.make_vae_params(8, 1), x0)
     assert maxerr(video, g['video_unipc']) < 5e-5
+
+
+# ---- umT5 encoder ---------------------------------------------------------
+def test_t5_oracle_vs_reference(golden):
+    """oracle/t5.py against the imported reference T5Encoder (g7): fp32 exact to 1e-5; the bf16
+    emulation must sit as close to the fp32 truth as the reference's own bf16 run does."""
+    from oracle import t5 as ot5
+    g = golden('g7_t5')
+    P = W.make_t5_params(W.TINY_T5, 2)
+    L = g['ids'].shape[1]
+    assert (ot5.rel_buckets(L, L).numpy() == g['buckets']).all()
+    for b in range(g['ids'].shape[0]):
+        kl = int(g['mask'][b].sum())
+        ids = T(g['ids'][b])
+        truth = g['out_fp32'][b, :kl]
+        assert maxerr(ot5.t5_encode(P, W.TINY_T5, ids, kl, False), truth) < 1e-5
+        ob = ot5.t5_encode(P, W.TINY_T5, ids, kl, True)
+        ref_bf = g['out_bf16'][b, :kl].astype(np.float32)
+        assert rel_l2(ob, ref_bf) < 3e-2
+        assert rel_l2(ob, truth) < 1.25 * rel_l2(ref_bf, truth) + 1e-3
+
+
+def test_t5_product_bucket_table():
+    """the host table the product hands mg_t5_attn_bf16 equals the reference bucket matrix."""
+    from oracle import t5 as ot5
+    from wan.modules.t5 import relative_buckets
+    for n in (1, 2, 17, 24, 200, 512):
+        full, tab = ot5.rel_buckets(n, n), relative_buckets(n)
+        i, j = torch.meshgrid(torch.arange(n), torch.arange(n), indexing='ij')
+        assert tab.dtype == torch.int32 and tab.numel() == 2 * n - 1
+        assert (tab[(j - i) + n - 1].long() == full).all()
+
+
+def test_t5_state_dict_names():
+    from wan.modules.t5 import T5Encoder, umt5_xxl
+    cfg = {('vocab' if k == 'vocab_size' else k): v for k, v in W.TINY_T5.items()}
+    m = T5Encoder(**cfg)
+    assert sorted(m.state_dict()) == sorted(W.t5_param_shapes(W.TINY_T5))
+    m.load_state_dict(W.make_t5_params(W.TINY_T5, 2))
+    assert m.blocks[0].norm1.weight.dtype == torch.float32 and m.blocks[0].attn.q.weight.dtype == torch.bfloat16
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 4, dtype=torch.long))          # no CPU path
+    with pytest.raises(NotImplementedError):
+        umt5_xxl(encoder_only=False)
