@@ -454,8 +454,8 @@ def test_t5_kernels_vs_oracle(dev):
     out = torch.empty(5, 128, dtype=bf, device=dev)
     ops.embed_rows(tab.to(dev), ids.to(dev), out)
     assert torch.equal(out.cpu(), tab[ids])
-    a, b = W.randn((33, 257), 2).to(bf), (W.randn((33, 257), 3) * 2).to(bf)
-    o = torch.empty(33, 257, dtype=bf, device=dev)
+    a, b = W.randn((33, 264), 2).to(bf), (W.randn((33, 264), 3) * 2).to(bf)
+    o = torch.empty(33, 264, dtype=bf, device=dev)
     ops.ew_bf16(a.to(dev), b.to(dev), o, 0)
     assert torch.equal(o.cpu(), (a.float() + b.float()).to(bf))
     ops.ew_bf16(a.to(dev), b.to(dev), o, 1)
