@@ -138,6 +138,7 @@ class WanModel(nn.Module):
         self.head = _Head(dim, math.prod(self.patch_size) * out_dim, dv)
         # sequence-parallel placement, installed by wan.distributed (Ulysses); 1 = single GPU
         self.sp_size, self.sp_rank, self.sp_group = 1, 0, None
+        self.sp_force = False   # run the Ulysses collectives even on a 1-rank group (RCCL smoke test)
         self._packed = None
         self._ws = {}
         self._rope = {}
@@ -271,7 +272,7 @@ class WanModel(nn.Module):
             if hd == 128:   # K / V packed into 64-key tiles (operand layout of the MFMA attention kernel)
                 n_pk = ops.packed_kv_numel(Ltot, self.num_heads // self.sp_size)
                 ws['kp'], ws['vp'] = e(n_pk), e(n_pk)
-            if self.sp_size > 1:
+            if self.sp_size > 1 or self.sp_force:
                 n_loc = self.num_heads // self.sp_size
                 ws['qg'], ws['kg'], ws['vg'] = e(Ltot, n_loc * hd), e(Ltot, n_loc * hd), e(Ltot, n_loc * hd)
                 ws['ag'] = e(Ltot, n_loc * hd)
@@ -340,7 +341,7 @@ class WanModel(nn.Module):
         sa = blk.self_attn
         ops.rmsnorm_rope(qkv[:, :d], sa.norm_q.weight, self.eps, hd, ws['q'], rope, grid, pos0)
         ops.rmsnorm_rope(qkv[:, d:2 * d], sa.norm_k.weight, self.eps, hd, ws['k'], rope, grid, pos0)
-        if self.sp_size == 1:
+        if self.sp_size == 1 and not self.sp_force:
             if hd == 128:
                 ops.pack_kv(ws['k'], qkv[:, 2 * d:], N, ws['kp'], ws['vp'])
                 self._attention(ws['q'], ws['kp'], ws['vp'], ws['a'], self._kv_valid, N)

@@ -1,0 +1,57 @@
+"""worker for the RCCL smoke test (-m gpu): ONE process, backend "nccl" (= RCCL), world_size 1.
+Exercises the exact torch.distributed calls of the production path (all_to_all_single /
+all_gather_into_tensor / broadcast / barrier on device tensors) and a forward with the sequence-
+parallel branch forced on a size-1 group, which must equal the plain forward bit for bit."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'moviigen1.1_amd'), os.path.join(ROOT, 'tests', 'golden')]
+
+import weights as W  # noqa: E402
+import wan  # noqa: E402
+from wan.distributed import fsdp, ulysses  # noqa: E402
+from wan.distributed.xdit_context_parallel import enable_sequence_parallel  # noqa: E402
+
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+os.environ.setdefault('MASTER_PORT', '29577')
+torch.cuda.set_device(0)
+dev = torch.device('cuda:0')
+dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+G = dist.group.WORLD
+N, hd, L = 4, 128, 96
+x = torch.randn(L, 3 * N * hd, device=dev).bfloat16()
+out = torch.empty(L, N * hd, dtype=torch.bfloat16, device=dev)
+ulysses.seq_to_head(x[:, N * hd:2 * N * hd], out, G, 1, N, hd)
+assert torch.equal(out, x[:, N * hd:2 * N * hd])
+back = torch.empty_like(out)
+ulysses.head_to_seq(out, back, G, 1, N, hd)
+assert torch.equal(back, out)
+assert torch.equal(ulysses.all_gather_seq(out, G, 1), out)
+dist.barrier()
+print('RCCL_COLLECTIVES_OK', flush=True)
+
+cfg = W.SMALL_DIT_HD128
+m = wan.modules.WanModel(**cfg)
+m.load_state_dict(W.make_dit_params(cfg, 0))
+m = m.to(dev).eval()
+lat = W.randn((16, 2, 8, 8), 3).to(dev)
+ctx = W.randn((20, cfg['text_dim']), 4).to(dev)
+t = torch.tensor([500.0], device=dev)
+ref = m([lat], t=t, context=[ctx], seq_len=32)[0].clone()
+enable_sequence_parallel(m)
+assert m.sp_size == 1
+m.sp_force = True                       # take the Ulysses branch on the size-1 RCCL group
+got = m([lat], t=t, context=[ctx], seq_len=32)[0]
+assert torch.equal(got, ref), (got - ref).abs().max().item()
+print('RCCL_SP_BRANCH_OK', flush=True)
+m.sp_force = False
+m = fsdp.shard_model(m, device_id=0)
+got = m([lat], t=t, context=[ctx], seq_len=32)[0]
+assert torch.equal(got, ref)
+print('RCCL_FSDP_OK', flush=True)
+dist.destroy_process_group()

@@ -433,6 +433,20 @@ def test_sequence_parallel_two_ranks_one_gpu():
     assert 'SP_FSDP_OK rank0' in r.stdout and 'SP_FSDP_OK rank1' in r.stdout
 
 
+def test_rccl_backend_single_rank():
+    """the production transport: backend "nccl" (RCCL) with device tensors, world_size 1 — the same
+    collective calls and the Ulysses / sharded-weights branches of the forward, equal to the plain one."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tests', 'dist_rccl_worker.py')], capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    for tag in ('RCCL_COLLECTIVES_OK', 'RCCL_SP_BRANCH_OK', 'RCCL_FSDP_OK'):
+        assert tag in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 # ------------------------------------------------------------------------------------------------
 # umT5 encoder (SURVEY §8(f) rank 1)
 # ------------------------------------------------------------------------------------------------
