@@ -22,13 +22,13 @@
 // keys: P (bf16) is directly the B-operand of O^T = V^T.P^T, the A-operand the chunk
 // vp[kc][d] = V[8 keys][d].  Deferred rescale of O^T while no row maximum grew by 2^8.
 //
-// Schedule ("two-level lock-step", see the kernel): 8 waves x 32 queries, one barrier per 64-key
-// tile; the hot loop only knows the maximum-free softmax branch and leaves for an exact tile when its
-// check fails.  mg_attn_set_variant: 0 = fragment reads scheduled by hipcc (4-deep ring, default),
-// 1 = hand-issued ds_read_b128 ring, 8 deep, counted lgkmcnt.  What was measured and dropped in
-// round 1 (ping-pong role split, intra-wave pipelined softmax, accumulator rotation on/off: all
-// within 960-1095 TFLOP/s) is archived in experiments/attn_hd128_schedules_r01.hip; DESIGN.md 3.1
-// has the s_memtime breakdown that explains why.
+// Schedules (mg_attn_set_variant):
+//   0  lock-step : 8 waves x 32 queries, one barrier per tile, all waves in the same phase.
+//   1  ping-pong : same tiling; waves 4-7 run one barrier interval behind waves 0-3, every interval
+//                  is either a vector segment (softmax of tile t) or a matrix segment
+//                  (P.V(t) ; S^T(t+1), 32 MFMAs, fragment reads DEPTH ahead): on each SIMD one wave
+//                  feeds the matrix pipe while its partner does softmax.
+#include <type_traits>
 #include "common.h"
 #include "../../include/moviigen_hip.h"
 
@@ -251,8 +251,341 @@ MG_DEV void att_matrix(AttState& s, const bf16x8_t (&qf)[8], const char* smem, i
     }
 }
 
+template <bool LAZY, int VARIANT, int DEPTH, bool ASM>
+__global__ __launch_bounds__(ATT_THREADS, 2) void attn_hd128_kernel(
+    const uint16_t* __restrict__ q, int64_t ldq, const uint16_t* __restrict__ kp, const uint16_t* __restrict__ vp,
+    uint16_t* __restrict__ o, int64_t ldo, int64_t Lq, int64_t Lk, int heads, float c_log2, int nqb) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
+
+    const int bid = blockIdx.x;
+    const int head = bid / nqb;
+    const int qb = bid - head * nqb;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;
+    const int lane = tid & 63, l31 = lane & 31, g = lane >> 5;
+
+    const int64_t qrow_raw = (int64_t)qb * ATT_QB + wave * 32 + l31;
+    const int64_t qrow = qrow_raw < Lq ? qrow_raw : Lq - 1;
+    bf16x8_t qf[8];
+    {
+        const uint16_t* qp = q + qrow * ldq + head * 128 + g * 8;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) qf[kk] = att_bf(*(const u32x4_t*)(qp + kk * 16));
+    }
+
+    const int nkv = (int)((Lk + ATT_KV - 1) / ATT_KV);
+    // LDS-DMA: tile = 16 contiguous KiB; wave w copies pieces 2w, 2w+1 of the K tile and of the V tile
+    const uint16_t* k_src = kp + ((int64_t)head * nkv) * 8192 + wave * 1024 + lane * 8;
+    const uint16_t* v_src = vp + ((int64_t)head * nkv) * 8192 + wave * 1024 + lane * 8;
+    auto dma = [&](int tk, int tv) __attribute__((always_inline)) {
+        if (tk < nkv) {
+            char* dst = smem + K_OFF(tk & 1) + wave * 2048;
+            att_glds16(k_src + (int64_t)tk * 8192, dst);
+            att_glds16(k_src + (int64_t)tk * 8192 + 512, dst + 1024);
+        }
+        if (tv < nkv) {
+            char* dst = smem + V_OFF(tv & 1) + wave * 2048;
+            att_glds16(v_src + (int64_t)tv * 8192, dst);
+            att_glds16(v_src + (int64_t)tv * 8192 + 512, dst + 1024);
+        }
+    };
+
+    const int kperm = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
+    const int kbase = g * 1024 + kperm * 16;
+    const int vbase = g * 2048 + l31 * 16;
+    const unsigned lds0 = (unsigned)(uintptr_t)(att_lptr_t)smem;   // LDS byte address of the workgroup's array
+    const unsigned lds_k = lds0 + kbase, lds_v = lds0 + vbase;
+
+    AttState s;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s.ot[d][e] = 0.f;
+    s.m_run = -1e30f;
+    s.l_run = 0.f;
+
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) asm volatile("" : "+v"(qf[kk]));  // retire the Q loads before any loop
+
+    if (VARIANT == 0) {
+        // ------------------------------ lock-step ------------------------------------------------
+        dma(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        auto tile = [&](int t, auto parity) __attribute__((always_inline)) {
+            constexpr int P = decltype(parity)::value;
+            dma(t + 1, t + 1);                                   // into the other slots, lands under the MFMAs
+            if constexpr (ASM) att_matrix_asm<16, 32, DEPTH, P, P>(s, qf, lds_v, lds_k);
+            else att_matrix<16, 32, DEPTH>(s, qf, smem, kbase, vbase, P, P);   // S^T(t)
+            const int lim = (int)((Lk - (int64_t)t * ATT_KV) < ATT_KV ? (Lk - (int64_t)t * ATT_KV) : ATT_KV);
+            if (!LAZY || __builtin_expect(!att_softmax_fast<0>(s, lim, g, c_log2), 0)) {
+                if (LAZY) att_matrix<16, 32, DEPTH>(s, qf, smem, kbase, vbase, P, P);   // S^T(t) again: the fast branch consumed it
+                att_softmax_exact<0>(s, lim, g, c_log2);
+            }
+            if constexpr (ASM) att_matrix_asm<0, 16, DEPTH, P, P>(s, qf, lds_v, lds_k);
+            else att_matrix<0, 16, DEPTH>(s, qf, smem, kbase, vbase, P, P);    // O^T += V^T(t).P^T
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        };
+        int t = 0;
+        for (; t + 1 < nkv; t += 2) {
+            tile(t, std::integral_constant<int, 0>{});
+            tile(t + 1, std::integral_constant<int, 1>{});
+        }
+        if (t < nkv) tile(t, std::integral_constant<int, 0>{});
+    } else {
+        // ------------------------------ ping-pong ------------------------------------------------
+        // K(0), V(0), K(1) resident; both groups run the same stream, group B one barrier behind.
+        dma(0, 0);
+        dma(1, nkv);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (grp == 1) __syncthreads();
+        if constexpr (ASM) att_matrix_asm<16, 32, DEPTH, 0, 0>(s, qf, lds_v, lds_k);
+        else att_matrix<16, 32, DEPTH>(s, qf, smem, kbase, vbase, 0, 0);       // S^T(0)
+        __syncthreads();
+        auto tile = [&](int t, auto parity) __attribute__((always_inline)) {
+            constexpr int P = decltype(parity)::value;
+            // vector segment: softmax(t).  Interval 2t+1 for group B = where K(t)/V(t-1) slots die.
+            // A refill issued in one segment is only needed two intervals later, so it is retired
+            // (vmcnt(0)) at the END OF THE FOLLOWING segment of the issuing wave — the DMA flies
+            // for a whole matrix segment.  Raw s_barrier: __syncthreads() would drain it at once.
+            if (grp == 1) dma(t + 2, t + 1);
+            const int lim = (int)((Lk - (int64_t)t * ATT_KV) < ATT_KV ? (Lk - (int64_t)t * ATT_KV) : ATT_KV);
+            if (!LAZY || __builtin_expect(!att_softmax_fast<0>(s, lim, g, c_log2), 0)) {
+                if (LAZY) att_matrix<16, 32, DEPTH>(s, qf, smem, kbase, vbase, P, P);   // K(t) is still resident
+                att_softmax_exact<0>(s, lim, g, c_log2);
+            }
+            if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // A's refill from its last matrix segment
+            __builtin_amdgcn_s_barrier();
+            // matrix segment: P.V(t) [V slot P] ; S^T(t+1) [K slot 1-P]
+            if (grp == 0) dma(t + 2, t + 1);
+            // branch-free on purpose: for the last tile the S^T(t+1) half multiplies stale LDS into
+            // registers nobody reads (16 wasted MFMAs per workgroup); a conditional here makes hipcc
+            // merge two definitions of the accumulators and spill ~60 VGPRs.
+            // (s_setprio(2) around this segment was measured: -2..-6 %, not kept)
+            if constexpr (ASM) att_matrix_asm<0, 32, DEPTH, P, 1 - P>(s, qf, lds_v, lds_k);
+            else att_matrix<0, 32, DEPTH>(s, qf, smem, kbase, vbase, P, 1 - P);
+            if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // B's refill from its vector segment
+            __builtin_amdgcn_s_barrier();
+        };
+        int t = 0;
+        for (; t + 1 < nkv; t += 2) {
+            tile(t, std::integral_constant<int, 0>{});
+            tile(t + 1, std::integral_constant<int, 1>{});
+        }
+        if (t < nkv) tile(t, std::integral_constant<int, 0>{});
+        if (grp == 0) __syncthreads();
+    }
+
+    const float l_tot = s.l_run + __shfl_xor(s.l_run, 32, 64);
+    const float inv = 1.f / l_tot;
+    if (qrow_raw < Lq) {
+        uint16_t* op = o + qrow_raw * ldo + head * 128 + g * 4;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                uint2 pk;
+                pk.x = pack_bf2(s.ot[d][rq * 4 + 0] * inv, s.ot[d][rq * 4 + 1] * inv);
+                pk.y = pack_bf2(s.ot[d][rq * 4 + 2] * inv, s.ot[d][rq * 4 + 3] * inv);
+                *(uint2*)(op + d * 32 + rq * 8) = pk;
+            }
+    }
+}
+
 // -------------------------------------------------------------------------------------------------
-// The kernel, "two-level": lock-step tiles, but the exact softmax (true maximum, rescale of O^T) is
+// Schedule 4, "pipelined": every wave overlaps ITS OWN softmax with ITS OWN MFMAs.
+//
+// Schedules 0-3 run bare 16/32-MFMA segments and a bare ~135-instruction softmax; with the two
+// waves of a SIMD in the same phase (0) the segment times add, and the role split (1) pays barrier
+// and arbitration costs.  A VALU instruction issued between two MFMAs of the same wave is almost
+// free (MI355X_MICROARCH.md: fillers beside MFMAs), so stage s (tile s) is software-pipelined:
+//
+//     n =  0.. 7   S0 = K(s)[keys  0..31].Q^T                        (8 MFMAs)
+//     n =  8..15   S1 = K(s)[keys 32..63].Q^T   |  exp/sum/max/cvt of S0, 2 elements per MFMA
+//     n = 16..31   O^T += V^T(s-1).P^T(s-1)     |  same for S1, then the cross-lane max + vote
+//
+// P(s) is produced against the running reference m_run (att_softmax, LAZY branch), so the
+// exponentials never wait for a tile maximum; the per-lane row sum validates it at the end of the
+// stage, and on failure the exact branch of att_softmax redoes the tile from the S registers,
+// rescaling O^T (which by then includes tile s-1) and l.  P is double-buffered
+// (pf[s&1]); tile 0, a ragged last tile and the final P.V run the plain segments of schedule 0.
+// -------------------------------------------------------------------------------------------------
+MG_DEV void att_spec_pair(const f32x16_t& sv, int j, float c_log2, float mc, float& psum, u32x4_t (&w)[2]) {
+    const float a = sv[2 * j], b = sv[2 * j + 1];
+    const float pa = __builtin_amdgcn_exp2f(a * c_log2 - mc), pb = __builtin_amdgcn_exp2f(b * c_log2 - mc);
+    psum += pa;
+    psum += pb;
+    unsigned pk = pack_bf2(pa, pb);
+    // opaque use: without it LLVM sinks the whole speculative softmax into the `ok` branch after the MFMAs
+    asm volatile("" : "+v"(pk), "+v"(psum));
+    w[j >> 2][j & 3] = pk;
+}
+
+template <int P, bool LAZY, int DEPTH>
+MG_DEV void att_stage_pipe(AttState& s, const bf16x8_t (&qf)[8], const char* smem, int kbase, int vbase, int g,
+                           float c_log2) {
+    constexpr int KS = P, VS = 1 - P;   // K(s) lives in slot s&1, V(s-1) in slot (s-1)&1
+    bf16x8_t f[DEPTH];
+    auto frag = [&](int m) __attribute__((always_inline)) -> const char* {   // stage item m: 0..15 S^T (kb = m>>3, kk = m&7), 16..31 P.V
+        if (m < 16) return smem + K_OFF(KS) + kbase + (m & 7) * 2048 + (m >> 3) * 512;
+        return att_frag(smem, kbase, vbase, m - 16, VS, KS);
+    };
+#pragma unroll
+    for (int i = 0; i < DEPTH; ++i) f[i] = *(const bf16x8_t*)frag(i);
+    __builtin_amdgcn_sched_barrier(0);
+    const float mc = s.m_run * c_log2;
+    float psum0 = 0.f, psum1 = 0.f;
+    u32x4_t w0[2], w1[2];
+#pragma unroll
+    for (int n = 0; n < 32; ++n) {
+        const int r = n % DEPTH;
+        if (n < 16) {
+            const int kb = n >> 3;
+            if ((n & 7) == 0) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) s.st[kb][e] = 0.f;
+            }
+            s.st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[r], qf[n & 7], s.st[kb], 0, 0, 0);
+        } else {
+            const int i = n - 16;
+            s.ot[att_pv_d(i)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[r], s.pf[1 - P][att_pv_kb(i)][att_pv_h(i)], s.ot[att_pv_d(i)], 0, 0, 0);
+        }
+        if (n + DEPTH < 32) f[r] = *(const bf16x8_t*)frag(n + DEPTH);
+        if (n >= 9 && n < 17) att_spec_pair(s.st[0], n - 9, c_log2, mc, psum0, w0);
+        if (n >= 17 && n < 25) att_spec_pair(s.st[1], n - 17, c_log2, mc, psum1, w1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const float psum = psum0 + psum1;
+    if (LAZY && __builtin_expect(__all(psum <= 256.f), 1)) {
+        s.l_run += psum;
+        s.pf[P][0][0] = att_bf(w0[0]);
+        s.pf[P][0][1] = att_bf(w0[1]);
+        s.pf[P][1][0] = att_bf(w1[0]);
+        s.pf[P][1][1] = att_bf(w1[1]);
+    } else {
+        att_matrix<16, 32, DEPTH>(s, qf, smem, kbase, vbase, VS, KS);   // the speculative pass consumed S^T(s)
+        att_softmax_exact<P>(s, ATT_KV, g, c_log2);
+    }
+}
+
+template <bool LAZY, int DEPTH>
+__global__ __launch_bounds__(ATT_THREADS, 2) void attn_hd128_pipe_kernel(
+    const uint16_t* __restrict__ q, int64_t ldq, const uint16_t* __restrict__ kp, const uint16_t* __restrict__ vp,
+    uint16_t* __restrict__ o, int64_t ldo, int64_t Lq, int64_t Lk, int heads, float c_log2, int nqb) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
+    const int bid = blockIdx.x;
+    const int head = bid / nqb;
+    const int qb = bid - head * nqb;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, l31 = lane & 31, g = lane >> 5;
+
+    const int64_t qrow_raw = (int64_t)qb * ATT_QB + wave * 32 + l31;
+    const int64_t qrow = qrow_raw < Lq ? qrow_raw : Lq - 1;
+    bf16x8_t qf[8];
+    {
+        const uint16_t* qp = q + qrow * ldq + head * 128 + g * 8;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) qf[kk] = att_bf(*(const u32x4_t*)(qp + kk * 16));
+    }
+    const int nkv = (int)((Lk + ATT_KV - 1) / ATT_KV);
+    const uint16_t* k_src = kp + ((int64_t)head * nkv) * 8192 + wave * 1024 + lane * 8;
+    const uint16_t* v_src = vp + ((int64_t)head * nkv) * 8192 + wave * 1024 + lane * 8;
+    auto dma = [&](int tk, int tv) __attribute__((always_inline)) {
+        if (tk < nkv) {
+            char* dst = smem + K_OFF(tk & 1) + wave * 2048;
+            att_glds16(k_src + (int64_t)tk * 8192, dst);
+            att_glds16(k_src + (int64_t)tk * 8192 + 512, dst + 1024);
+        }
+        if (tv < nkv) {
+            char* dst = smem + V_OFF(tv & 1) + wave * 2048;
+            att_glds16(v_src + (int64_t)tv * 8192, dst);
+            att_glds16(v_src + (int64_t)tv * 8192 + 512, dst + 1024);
+        }
+    };
+    const int kperm = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
+    const int kbase = g * 1024 + kperm * 16;
+    const int vbase = g * 2048 + l31 * 16;
+
+    AttState s;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s.ot[d][e] = 0.f;
+    s.m_run = -1e30f;
+    s.l_run = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) asm volatile("" : "+v"(qf[kk]));
+
+    auto fence = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+    // stage s needs K(s) [slot s&1] and V(s-1) [slot (s-1)&1]; it refills K(s+1) and V(s)
+    dma(0, nkv);
+    fence();
+    const int last_lim = (int)(Lk - (int64_t)(nkv - 1) * ATT_KV);      // keys in the last tile, 1..64
+    {   // stage 0: S^T(0), exact softmax -> pf[0]
+        dma(1, 0);
+        att_matrix<16, 32, DEPTH>(s, qf, smem, kbase, vbase, 0, 0);
+        att_softmax_exact<0>(s, nkv == 1 ? last_lim : ATT_KV, g, c_log2);
+        fence();
+    }
+    const int npipe = last_lim < ATT_KV ? nkv - 1 : nkv;               // stages [1, npipe) are full tiles
+    int st = 1;
+    for (; st + 1 < npipe; st += 2) {
+        dma(st + 1, st);
+        att_stage_pipe<1, LAZY, DEPTH>(s, qf, smem, kbase, vbase, g, c_log2);
+        fence();
+        dma(st + 2, st + 1);
+        att_stage_pipe<0, LAZY, DEPTH>(s, qf, smem, kbase, vbase, g, c_log2);
+        fence();
+    }
+    if (st < npipe) {
+        dma(st + 1, st);
+        att_stage_pipe<1, LAZY, DEPTH>(s, qf, smem, kbase, vbase, g, c_log2);
+        fence();
+        ++st;
+    }
+    if (st < nkv) {   // ragged last tile (st == nkv-1 >= 1): plain segments, masked exact softmax
+        dma(st + 1, st);
+        if (st & 1) {
+            att_matrix<0, 16, DEPTH, 0>(s, qf, smem, kbase, vbase, 0, 1);      // P.V(st-1): V slot 0, pf[0]
+            att_matrix<16, 32, DEPTH>(s, qf, smem, kbase, vbase, 0, 1);        // S^T(st): K slot 1
+            att_softmax_exact<1>(s, last_lim, g, c_log2);
+        } else {
+            att_matrix<0, 16, DEPTH, 1>(s, qf, smem, kbase, vbase, 1, 0);
+            att_matrix<16, 32, DEPTH>(s, qf, smem, kbase, vbase, 1, 0);
+            att_softmax_exact<0>(s, last_lim, g, c_log2);
+        }
+        fence();
+        ++st;
+    }
+    // final stage (st == nkv): P.V(nkv-1)
+    if ((nkv - 1) & 1) att_matrix<0, 16, DEPTH, 1>(s, qf, smem, kbase, vbase, 1, 0);
+    else att_matrix<0, 16, DEPTH, 0>(s, qf, smem, kbase, vbase, 0, 0);
+
+    const float l_tot = s.l_run + __shfl_xor(s.l_run, 32, 64);
+    const float inv = 1.f / l_tot;
+    if (qrow_raw < Lq) {
+        uint16_t* op = o + qrow_raw * ldo + head * 128 + g * 4;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                uint2 pk;
+                pk.x = pack_bf2(s.ot[d][rq * 4 + 0] * inv, s.ot[d][rq * 4 + 1] * inv);
+                pk.y = pack_bf2(s.ot[d][rq * 4 + 2] * inv, s.ot[d][rq * 4 + 3] * inv);
+                *(uint2*)(op + d * 32 + rq * 8) = pk;
+            }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Schedule 5, "two-level": lock-step tiles, but the exact softmax (true maximum, rescale of O^T) is
 // moved OUT of the hot loop.  A rescale inside the tile loop makes O^T (64 VGPRs) a phi of two
 // definitions and hipcc pays 32 v_mov_b64 per tile on the hot edge; here the inner loop only knows
 // the fast branch (att_softmax_fast: no maximum, no rescale) and LEAVES when its check fails; the
@@ -260,7 +593,7 @@ MG_DEV void att_matrix(AttState& s, const bf16x8_t (&qf)[8], const char* smem, i
 // folded into the per-lane base), so there is no parity unrolling.
 // -------------------------------------------------------------------------------------------------
 template <bool LAZY, int DEPTH, bool PROF = false, bool ASM = false>
-__global__ __launch_bounds__(ATT_THREADS, 2) void attn_hd128_kernel(
+__global__ __launch_bounds__(ATT_THREADS, 2) void attn_hd128_v5_kernel(
     const uint16_t* __restrict__ q, int64_t ldq, const uint16_t* __restrict__ kp, const uint16_t* __restrict__ vp,
     uint16_t* __restrict__ o, int64_t ldo, int64_t Lq, int64_t Lk, int heads, float c_log2, int nqb,
     unsigned long long* __restrict__ prof) {
@@ -471,16 +804,39 @@ extern "C" int mg_attn_fwd_bf16_hd128(const uint16_t* q, int64_t ldq, const uint
     const float c_log2 = scale * 1.4426950408889634f;
     const dim3 grid((unsigned)(nqb * heads)), block(ATT_THREADS);
     hipStream_t st = (hipStream_t)stream;
-#define ATT_LAUNCH(LZ, DP, PROF, ASM) \
-    hipLaunchKernelGGL((attn_hd128_kernel<LZ, DP, PROF, ASM>), grid, block, 0, st, q, ldq, kp, vp, o, ldo, Lq, Lk, heads, c_log2, nqb, g_attn_prof)
-    if (g_attn_variant == 1) {
-        if (g_attn_prof) ATT_LAUNCH(true, 8, true, true);
-        else if (g_attn_lazy) ATT_LAUNCH(true, 8, false, true);
-        else ATT_LAUNCH(false, 8, false, true);
-    } else {
-        if (g_attn_prof) ATT_LAUNCH(true, 4, true, false);
-        else if (g_attn_lazy) ATT_LAUNCH(true, 4, false, false);
-        else ATT_LAUNCH(false, 4, false, false);
+#define ATT_LAUNCH(LZ, VAR, DP) \
+    hipLaunchKernelGGL((attn_hd128_kernel<LZ, (VAR) & 1, DP, ((VAR) >> 1) != 0>), grid, block, 0, st, q, ldq, kp, vp, o, ldo, Lq, Lk, heads, c_log2, nqb)
+    // variant bit 0: 0 lock-step / 1 ping-pong; bit 1: fragment reads by hipcc (0) or hand-issued asm (1)
+    if (g_attn_variant == 6) {
+        if (g_attn_prof)
+            hipLaunchKernelGGL((attn_hd128_v5_kernel<true, 8, true, true>), grid, block, 0, st, q, ldq, kp, vp, o, ldo, Lq, Lk, heads, c_log2, nqb, g_attn_prof);
+        else if (g_attn_lazy)
+            hipLaunchKernelGGL((attn_hd128_v5_kernel<true, 8, false, true>), grid, block, 0, st, q, ldq, kp, vp, o, ldo, Lq, Lk, heads, c_log2, nqb, nullptr);
+        else
+            hipLaunchKernelGGL((attn_hd128_v5_kernel<false, 8, false, true>), grid, block, 0, st, q, ldq, kp, vp, o, ldo, Lq, Lk, heads, c_log2, nqb, nullptr);
+        return mg_check_launch();
+    }
+    if (g_attn_variant == 5) {
+        if (g_attn_prof)
+            hipLaunchKernelGGL((attn_hd128_v5_kernel<true, 4, true>), grid, block, 0, st, q, ldq, kp, vp, o, ldo, Lq, Lk, heads, c_log2, nqb, g_attn_prof);
+        else if (g_attn_lazy)
+            hipLaunchKernelGGL((attn_hd128_v5_kernel<true, 4>), grid, block, 0, st, q, ldq, kp, vp, o, ldo, Lq, Lk, heads, c_log2, nqb, nullptr);
+        else
+            hipLaunchKernelGGL((attn_hd128_v5_kernel<false, 4>), grid, block, 0, st, q, ldq, kp, vp, o, ldo, Lq, Lk, heads, c_log2, nqb, nullptr);
+        return mg_check_launch();
+    }
+    if (g_attn_variant == 4) {
+        if (g_attn_lazy)
+            hipLaunchKernelGGL((attn_hd128_pipe_kernel<true, 4>), grid, block, 0, st, q, ldq, kp, vp, o, ldo, Lq, Lk, heads, c_log2, nqb);
+        else
+            hipLaunchKernelGGL((attn_hd128_pipe_kernel<false, 4>), grid, block, 0, st, q, ldq, kp, vp, o, ldo, Lq, Lk, heads, c_log2, nqb);
+        return mg_check_launch();
+    }
+    switch (g_attn_variant & 3) {
+        case 3: if (g_attn_lazy) ATT_LAUNCH(true, 3, 6); else ATT_LAUNCH(false, 3, 6); break;
+        case 2: if (g_attn_lazy) ATT_LAUNCH(true, 2, 4); else ATT_LAUNCH(false, 2, 4); break;
+        case 1: if (g_attn_lazy) ATT_LAUNCH(true, 1, 4); else ATT_LAUNCH(false, 1, 4); break;
+        default: if (g_attn_lazy) ATT_LAUNCH(true, 0, 4); else ATT_LAUNCH(false, 0, 4); break;
     }
 #undef ATT_LAUNCH
     return mg_check_launch();

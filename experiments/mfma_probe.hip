@@ -1,0 +1,136 @@
+// Issue-model probe for gfx950 (not product code): what does ONE SIMD sustain when two co-resident
+// waves stream v_mfma_f32_32x32x16_bf16 with N VALU / transcendental / ds_read_b128 fillers per MFMA?
+// Reports TFLOP/s (wall), shader cycles per MFMA per wave (s_memtime) and the effective clock.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 experiments/mfma_probe.hip -o moviigen1.1_amd/lib/mfma_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+
+template <int NACC, int FILL, int TRANS, int LDSR, int WAVES, int LDSKB = 64>
+__global__ __launch_bounds__(WAVES * 64, 2) void probe(const u32x4_t* __restrict__ in, float* __restrict__ out,
+                                                      int iters, unsigned long long* __restrict__ cyc) {
+    __shared__ __attribute__((aligned(16))) char smem[LDSKB * 1024];   // 96 KiB: one workgroup per CU
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i < 4096; i += WAVES * 64) ((u32x4_t*)smem)[i] = in[i];
+    __syncthreads();
+    bf16x8_t a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a[i] = __builtin_bit_cast(bf16x8_t, in[(tid * 4 + i) & 4095]);
+        b[i] = __builtin_bit_cast(bf16x8_t, in[(tid * 4 + i + 1777) & 4095]);
+    }
+    f32x16_t acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    float x[8], y[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = 0.001f * (lane + i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y[i] = -0.01f * (lane + i);
+    const float c = 0.999f;
+    const char* lp = smem + lane * 16;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            acc[j % NACC] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j & 3], b[(j >> 2) & 3], acc[j % NACC], 0, 0, 0);
+            if (LDSR) a[(j + 3) & 3] = *(const bf16x8_t*)(lp + ((j * 1024 + it * 16384) & 0xfc00));
+#pragma unroll
+            for (int f = 0; f < FILL; ++f) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(x[f]) : "v"(c));
+#pragma unroll
+            for (int t = 0; t < TRANS; ++t) asm volatile("v_exp_f32 %0, %0" : "+v"(y[t]));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float r = 0.f;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) r += acc[i][e];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r += x[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r += y[i];
+    out[blockIdx.x * (WAVES * 64) + tid] = r;
+    if (tid == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+template <int NACC, int FILL, int TRANS, int LDSR, int WAVES, int LDSKB = 64>
+void run(const u32x4_t* in, float* out, unsigned long long* cyc, int zero) {
+    const int iters = 20000, grid = 256 * 4;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL((probe<NACC, FILL, TRANS, LDSR, WAVES, LDSKB>), dim3(grid), dim3(WAVES * 64), 0, 0, in, out, 2000, cyc);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL((probe<NACC, FILL, TRANS, LDSR, WAVES, LDSKB>), dim3(grid), dim3(WAVES * 64), 0, 0, in, out, iters, cyc);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<unsigned long long> h(grid);
+    CK(hipMemcpy(h.data(), cyc, grid * 8, hipMemcpyDeviceToHost));
+    double cs = 0;
+    for (auto v : h) cs += (double)v;
+    cs /= grid;
+    const double flops = (double)grid * WAVES * iters * 16 * 32768.0;
+    // each CU runs grid/256 workgroups back to back (one resident at 64 KiB LDS + launch bounds... two may fit)
+    printf("acc=%d fill=%d trans=%d lds=%d waves=%d/CU %s: %8.1f TF/s  %6.1f cyc/MFMA/wave (memtime)  wall %.2f ms\n", NACC, FILL, TRANS,
+           LDSR, LDSKB > 64 ? WAVES : 2 * WAVES > 8 ? 8 : 2 * WAVES, zero ? "zeros " : "random", flops / (ms * 1e-3) / 1e12, cs / (iters * 16.0), ms);
+}
+
+int main() {
+    u32x4_t* in; float* out; unsigned long long* cyc;
+    CK(hipMalloc(&in, 65536)); CK(hipMalloc(&out, 1024 * 512 * 4)); CK(hipMalloc(&cyc, 1024 * 8));
+    std::vector<unsigned short> h(32768);
+    for (int z = 0; z < 2; ++z) {
+        srand(1);
+        for (auto& v : h) {
+            float f = z ? 0.f : ((rand() % 2001) - 1000) / 1000.0f;
+            unsigned u; memcpy(&u, &f, 4);
+            v = (unsigned short)(u >> 16);
+        }
+        CK(hipMemcpy(in, h.data(), 65536, hipMemcpyHostToDevice));
+        run<4, 0, 0, 0, 8>(in, out, cyc, z);
+        run<4, 0, 0, 0, 4>(in, out, cyc, z);
+        if (z) break;
+        run<1, 0, 0, 0, 8>(in, out, cyc, z);
+        run<2, 0, 0, 0, 8>(in, out, cyc, z);
+        run<4, 0, 0, 1, 8>(in, out, cyc, z);
+        run<4, 2, 0, 1, 8>(in, out, cyc, z);
+        run<4, 4, 0, 1, 8>(in, out, cyc, z);
+        run<4, 6, 0, 1, 8>(in, out, cyc, z);
+        run<4, 8, 0, 1, 8>(in, out, cyc, z);
+        run<4, 3, 1, 1, 8>(in, out, cyc, z);
+        run<4, 4, 2, 1, 8>(in, out, cyc, z);
+        run<2, 4, 2, 1, 8>(in, out, cyc, z);
+        run<1, 4, 2, 1, 8>(in, out, cyc, z);
+        run<4, 4, 2, 1, 4>(in, out, cyc, z);
+        run<4, 8, 4, 1, 4>(in, out, cyc, z);
+        // ONE wave per SIMD (4 waves per CU, 96 KiB LDS keeps a second workgroup out)
+        run<4, 0, 0, 0, 4, 96>(in, out, cyc, z);
+        run<4, 0, 0, 1, 4, 96>(in, out, cyc, z);
+        run<4, 2, 0, 1, 4, 96>(in, out, cyc, z);
+        run<4, 4, 0, 1, 4, 96>(in, out, cyc, z);
+        run<4, 5, 0, 1, 4, 96>(in, out, cyc, z);
+        run<4, 6, 0, 1, 4, 96>(in, out, cyc, z);
+        run<4, 8, 0, 1, 4, 96>(in, out, cyc, z);
+        run<4, 3, 1, 1, 4, 96>(in, out, cyc, z);
+        run<4, 4, 2, 1, 4, 96>(in, out, cyc, z);
+        run<4, 2, 2, 0, 4, 96>(in, out, cyc, z);
+        run<1, 4, 0, 1, 4, 96>(in, out, cyc, z);
+        run<2, 4, 0, 1, 4, 96>(in, out, cyc, z);
+    }
+    return 0;
+}

@@ -95,8 +95,10 @@ int mg_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw,
                  const float* bias, int64_t M, int N, int K, int epilogue, void* out,
                  int64_t ldo, const float* gate, void* stream);
 
-/* Tile schedule of mg_gemm_bf16: 2 (default) = 256x128x64 tile, 8 waves, 3-stage LDS ring with
- * counted vmcnt; 1 = 128x128x64 tile, 4 waves, 2 stages.  Same results bit for bit. */
+/* Tile schedule of mg_gemm_bf16: 3 (default) = 256x256x64 tile, 8 waves, 2 LDS stages, LDS-DMA
+ * pieces spread between the MFMAs (M > 256 and N > 128, else falls to 2); 2 = 256x128x64 tile,
+ * 8 waves, 3-stage LDS ring with counted vmcnt (M > 128, else 1); 1 = 128x128x64 tile, 4 waves,
+ * 2 stages.  Same results bit for bit. */
 void mg_gemm_set_variant(int variant);
 
 /* softmax(q k^T * scale) v, non-causal, keys >= Lk masked; bf16 in/out, fp32 accumulate,
@@ -119,11 +121,9 @@ int mg_attn_fwd_bf16_generic(const uint16_t* q, int64_t ldq, const uint16_t* k, 
 /* Tuning knob: 1 (default) = defer the online-softmax rescale while no row maximum grew by more
  * than 2^8 since the last rescale (P <= 256 in bf16); 0 = rescale every tile. */
 void mg_attn_set_lazy_rescale(int on);
-/* Schedule of mg_attn_fwd_bf16_hd128, two bits.  bit 0: 0 = lock-step (8 waves in the same phase),
- * 1 = ping-pong (waves 4-7 one barrier interval behind waves 0-3: on each SIMD one wave is in its
- * 32-MFMA matrix segment while its partner does softmax).  bit 1: 0 = LDS fragment reads scheduled
- * by hipcc, 1 = hand-issued (inline-asm ds_read_b128 ring with counted lgkmcnt).  Same math in all
- * four; default 0 = the fastest measured. */
+/* Fragment-read flavour of mg_attn_fwd_bf16_hd128 (same math, same two-level lock-step schedule):
+ * 0 = LDS fragment reads scheduled by hipcc, 4-deep ring (default, fastest measured);
+ * 1 = hand-issued inline-asm ds_read_b128 ring, 8 deep, counted lgkmcnt.  Other values select 0. */
 void mg_attn_set_variant(int variant);
 
 /* ------------------------------------------------------------------------------------------

@@ -10,6 +10,9 @@
 #include <string.h>
 #include <vector>
 #include "moviigen_hip.h"
+extern "C" void mg_attn_debug_profile(unsigned long long* dev_buf);
+extern "C" void mg_gemm_debug_profile(unsigned long long* dev_buf);
+extern "C" void mg_gemm3_debug_profile(unsigned long long* dev_buf);
 
 #define CK(x)                                                                      \
     do {                                                                           \
@@ -442,7 +445,7 @@ int main(int argc, char** argv) {
     CK(hipGetDeviceProperties(&prop, 0));
     printf("device: %s  CUs=%d  %s  abi=%d\n", prop.name, prop.multiProcessorCount, mg_version(), mg_abi_version());
     if (argc > 1 && !strcmp(argv[1], "attn")) {  // quick perf loop on the dominant kernel
-        for (int variant = 0; variant < 4; ++variant) {
+        for (int variant = 0; variant < 2; ++variant) {
             printf("== attention variant %d ==\n", variant);
             mg_attn_set_variant(variant);
             test_attn(300, 300, 2, 0, false, 1);
@@ -456,17 +459,53 @@ int main(int argc, char** argv) {
         printf("%s: %d failure(s)\n", n_fail ? "SELFTEST FAILED" : "SELFTEST OK", n_fail);
         return n_fail ? 1 : 0;
     }
+    if (argc > 1 && !strcmp(argv[1], "attnprof")) {  // s_memtime breakdown of schedule 5's hot loop
+        unsigned long long* buf;
+        CK(hipMalloc(&buf, 40 * 8));
+        CK(hipMemset(buf, 0, 40 * 8));
+        mg_attn_set_variant(argc > 2 ? atoi(argv[2]) : 0);
+        mg_attn_debug_profile(buf);
+        test_attn(75600, 75600, 8, 8, true, 1);
+        unsigned long long h[40];
+        CK(hipMemcpy(h, buf, sizeof h, hipMemcpyDeviceToHost));
+        for (int w = 0; w < 8; ++w) {
+            const double n = (double)h[w * 5 + 4];
+            printf("wave %d: tiles %.0f  S^T %.0f  softmax %.0f  P.V %.0f  fence %.0f  (cycles per tile)\n", w, n, h[w * 5] / n,
+                   h[w * 5 + 1] / n, h[w * 5 + 2] / n, h[w * 5 + 3] / n);
+        }
+        mg_attn_debug_profile(nullptr);
+        return 0;
+    }
     if (argc > 1 && !strcmp(argv[1], "attn1")) {  // single big launch set, for rocprofv3 --pmc passes
         mg_attn_set_variant(argc > 2 ? atoi(argv[2]) : 0);
         test_attn(75600, 75600, 8, 8, true, 1);
         return n_fail ? 1 : 0;
+    }
+    if (argc > 1 && !strcmp(argv[1], "gemmprof")) {  // s_memtime breakdown of the 256x128 GEMM k-loop
+        unsigned long long* buf;
+        CK(hipMalloc(&buf, 32 * 8));
+        CK(hipMemset(buf, 0, 32 * 8));
+        const int gv = argc > 2 ? atoi(argv[2]) : 2;
+        mg_gemm_set_variant(gv);
+        if (gv == 3) mg_gemm3_debug_profile(buf); else mg_gemm_debug_profile(buf);
+        test_gemm(75600, 5120, 5120, 0, 64, true);
+        unsigned long long h[32];
+        CK(hipMemcpy(h, buf, sizeof h, hipMemcpyDeviceToHost));
+        for (int w = 0; w < 8; ++w) {
+            const double n = (double)h[w * 4 + 3];
+            printf("wave %d: k-tiles %.0f  wait+barrier %.0f  stage issue %.0f  MFMA segment %.0f  (cycles per k-tile)\n", w, n,
+                   h[w * 4] / n, h[w * 4 + 1] / n, h[w * 4 + 2] / n);
+        }
+        mg_gemm_debug_profile(nullptr);
+        mg_gemm3_debug_profile(nullptr);
+        return 0;
     }
     if (argc > 1 && !strcmp(argv[1], "gemm1")) {
         test_gemm(75600, 5120, 5120, 0, 64, true);
         return n_fail ? 1 : 0;
     }
     if (argc > 1 && !strcmp(argv[1], "gemm")) {
-        for (int variant = 1; variant <= 2; ++variant) {
+        for (int variant = 1; variant <= 3; ++variant) {
             printf("== gemm variant %d ==\n", variant);
             mg_gemm_set_variant(variant);
             for (int epi = 0; epi < 4; ++epi) test_gemm(300, 256, 128, epi, 0, false);

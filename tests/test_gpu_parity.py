@@ -123,6 +123,26 @@ def test_gemm_epilogues(dev, M, N, K, epi):
     assert scale_err(out.float(), ref) < 1.2e-2
 
 
+@pytest.mark.parametrize('M,N,K', [(700, 520, 256), (257, 132, 64), (1030, 1284, 640)])
+def test_gemm_tile_variants_agree(dev, M, N, K):
+    """the three tile schedules (128x128, 256x128, 256x256) give the same bits, ragged edges included."""
+    from wan.backend import lib, ops
+    a = W.randn((M, K), 16).bfloat16().to(dev)
+    w = (W.randn((N, K), 17) * 0.05).bfloat16().to(dev)
+    b = W.randn((N,), 18).to(dev)
+    outs = []
+    try:
+        for v in (1, 2, 3):
+            lib.load().mg_gemm_set_variant(v)
+            o = torch.full((M + 1, N), -7.0, dtype=torch.float32, device=dev)      # guard row: no write past M
+            ops.gemm(a, w, b, ops.BIAS_F32, o[:M])
+            assert (o[M] == -7.0).all()
+            outs.append(o[:M].clone())
+    finally:
+        lib.load().mg_gemm_set_variant(3)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
 def test_gemm_rejects_bad_shapes(dev):
     from wan.backend import lib, ops
     a = torch.zeros(8, 96, dtype=torch.bfloat16, device=dev)      # K % 64 != 0
@@ -176,9 +196,9 @@ def test_attention_rescale_branch(dev, attn_variant):
     assert scale_err(outs[0], outs[1]) < 2e-2
 
 
-@pytest.fixture(params=[0, 1, 2, 3], ids=['lockstep', 'pingpong', 'lockstep_asm', 'pingpong_asm'])
+@pytest.fixture(params=[0, 1], ids=['hipcc_reads', 'asm_ring'])
 def attn_variant(request):
-    """run a test under both schedules of mg_attn_fwd_bf16_hd128."""
+    """run a test under both fragment-read flavours of mg_attn_fwd_bf16_hd128."""
     from wan.backend import lib
     lib.load().mg_attn_set_variant(request.param)
     yield request.param
@@ -357,7 +377,7 @@ def test_pipeline_cfg1(dev, golden, solver):
 # ------------------------------------------------------------------------------------------------
 # size-independent properties at BASELINE.json configs[1] sizes (L = 75 600, 40 heads, d = 5120)
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('variant', [0, 1, 2, 3])
+@pytest.mark.parametrize('variant', [0, 1])
 def test_fullsize_attention_properties(dev, variant):
     """both schedules (lock-step, ping-pong) of the MFMA attention kernel at the full 720p size."""
     from wan.backend import lib, ops
