@@ -121,9 +121,12 @@ int mg_attn_fwd_bf16_generic(const uint16_t* q, int64_t ldq, const uint16_t* k, 
 /* Tuning knob: 1 (default) = defer the online-softmax rescale while no row maximum grew by more
  * than 2^8 since the last rescale (P <= 256 in bf16); 0 = rescale every tile. */
 void mg_attn_set_lazy_rescale(int on);
-/* Fragment-read flavour of mg_attn_fwd_bf16_hd128 (same math, same two-level lock-step schedule):
- * 0 = LDS fragment reads scheduled by hipcc, 4-deep ring (default, fastest measured);
- * 1 = hand-issued inline-asm ds_read_b128 ring, 8 deep, counted lgkmcnt.  Other values select 0. */
+/* Kernel behind mg_attn_fwd_bf16_hd128 (same math in all):
+ * 0 = auto (default): 3 when Lk >= 2048 (self-attention), else 1;
+ * 1 = two-level lock-step kernel, 8 waves x 32 queries, LDS fragment reads scheduled by hipcc;
+ * 2 = same kernel with a hand-issued ds_read_b128 ring (8 deep, counted lgkmcnt);
+ * 3 = "w64": 4 waves x 64 queries, one wave per SIMD, software-pipelined in 32-key units
+ *     (csrc/attn_hd128_w64.hip).  Other values select 1. */
 void mg_attn_set_variant(int variant);
 
 /* ------------------------------------------------------------------------------------------

@@ -22,10 +22,12 @@
 // keys: P (bf16) is directly the B-operand of O^T = V^T.P^T, the A-operand the chunk
 // vp[kc][d] = V[8 keys][d].  Deferred rescale of O^T while no row maximum grew by 2^8.
 //
-// Schedule ("two-level lock-step", see the kernel): 8 waves x 32 queries, one barrier per 64-key
-// tile; the hot loop only knows the maximum-free softmax branch and leaves for an exact tile when its
-// check fails.  mg_attn_set_variant: 0 = fragment reads scheduled by hipcc (4-deep ring, default),
-// 1 = hand-issued ds_read_b128 ring, 8 deep, counted lgkmcnt.  What was measured and dropped in
+// Two kernels share this ABI.  This file: "two-level lock-step", 8 waves x 32 queries, one barrier per
+// 64-key tile; the hot loop only knows the maximum-free softmax branch and leaves for an exact tile when
+// its check fails.  attn_hd128_w64.hip: 4 waves x 64 queries, one wave per SIMD, software-pipelined.
+// mg_attn_set_variant: 0 = auto (w64 for Lk >= 2048, else two-level), 1 = two-level with fragment reads
+// scheduled by hipcc (4-deep ring), 2 = two-level with a hand-issued ds_read_b128 ring (8 deep,
+// counted lgkmcnt), 3 = w64.  What was measured and dropped in
 // round 1 (ping-pong role split, intra-wave pipelined softmax, accumulator rotation on/off: all
 // within 960-1095 TFLOP/s) is archived in experiments/attn_hd128_schedules_r01.hip; DESIGN.md 3.1
 // has the s_memtime breakdown that explains why.
@@ -452,6 +454,8 @@ extern "C" int mg_pack_kv_bf16(const uint16_t* k, int64_t ldk, const uint16_t* v
 static unsigned long long* g_attn_prof = nullptr;
 // debug hook (not in the public header): device buffer of 8 waves x 5 counters for schedule 5's PROF build
 extern "C" void mg_attn_debug_profile(unsigned long long* dev_buf) { g_attn_prof = dev_buf; }
+int mg_attn_w64_launch(const uint16_t* q, int64_t ldq, const uint16_t* kp, const uint16_t* vp, uint16_t* o, int64_t ldo,
+                       int64_t Lq, int64_t Lk, int heads, float c_log2, int nqb, hipStream_t st);
 static int g_attn_lazy = 1;
 static int g_attn_variant = 0;
 extern "C" void mg_attn_set_lazy_rescale(int on) { g_attn_lazy = on; }
@@ -471,9 +475,13 @@ extern "C" int mg_attn_fwd_bf16_hd128(const uint16_t* q, int64_t ldq, const uint
     const float c_log2 = scale * 1.4426950408889634f;
     const dim3 grid((unsigned)(nqb * heads)), block(ATT_THREADS);
     hipStream_t st = (hipStream_t)stream;
+    // 0 = auto: the one-wave-per-SIMD "w64" kernel for long key sequences (self-attention), the
+    // two-level lock-step kernel for short ones (cross-attention: 8 key tiles, prologue-dominated)
+    const int variant = g_attn_variant == 0 ? (Lk >= 2048 ? 3 : 1) : g_attn_variant;
+    if (variant == 3) return mg_attn_w64_launch(q, ldq, kp, vp, o, ldo, Lq, Lk, heads, c_log2, nqb, st);
 #define ATT_LAUNCH(LZ, DP, PROF, ASM) \
     hipLaunchKernelGGL((attn_hd128_kernel<LZ, DP, PROF, ASM>), grid, block, 0, st, q, ldq, kp, vp, o, ldo, Lq, Lk, heads, c_log2, nqb, g_attn_prof)
-    if (g_attn_variant == 1) {
+    if (variant == 2) {
         if (g_attn_prof) ATT_LAUNCH(true, 8, true, true);
         else if (g_attn_lazy) ATT_LAUNCH(true, 8, false, true);
         else ATT_LAUNCH(false, 8, false, true);

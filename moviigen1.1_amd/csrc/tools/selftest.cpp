@@ -12,6 +12,8 @@
 #include "moviigen_hip.h"
 extern "C" void mg_attn_debug_profile(unsigned long long* dev_buf);
 extern "C" void mg_gemm_debug_profile(unsigned long long* dev_buf);
+extern "C" void mg_attn_w64_debug(int flags);
+extern "C" void mg_attn_w64_profile(unsigned long long* dev_buf);
 extern "C" void mg_gemm3_debug_profile(unsigned long long* dev_buf);
 
 #define CK(x)                                                                      \
@@ -285,6 +287,7 @@ static void test_attn(int64_t Lq, int64_t Lk, int heads, int nsamp, bool timeit,
     const int64_t total = Lq * heads;
     const int64_t cnt = nsamp > 0 ? nsamp : total;
     std::vector<double> s(Lk);
+    int64_t worst_q = -1; int worst_h = -1, worst_d = -1; double worst_got = 0, worst_ref = 0;
     for (int64_t it = 0; it < cnt; ++it) {
         int64_t qi; int h;
         if (nsamp > 0) {
@@ -307,9 +310,11 @@ static void test_attn(int64_t Lq, int64_t Lk, int heads, int nsamp, bool timeit,
             double a = 0;
             for (int64_t j = 0; j < Lk; ++j) a += s[j] * bf2f(v[(size_t)j * ld + h * 128 + d]);
             a /= den;
-            err = fmax(err, fabs(bf2f(got[(size_t)qi * ld + h * 128 + d]) - a));
+            const double e1 = fabs(bf2f(got[(size_t)qi * ld + h * 128 + d]) - a);
+            if (e1 > err) { err = e1; worst_q = qi; worst_h = h; worst_d = d; worst_got = bf2f(got[(size_t)qi * ld + h * 128 + d]); worst_ref = a; }
         }
     }
+    if (err > 2e-2) printf("    worst: query %lld head %d d %d got %g ref %g\n", (long long)worst_q, worst_h, worst_d, worst_got, worst_ref);
     char nm[160];
     snprintf(nm, sizeof nm, "attn_fwd Lq%lld Lk%lld heads%d lazy%d", (long long)Lq, (long long)Lk, heads, lazy);
     report(nm, err, 2e-2);
@@ -445,7 +450,7 @@ int main(int argc, char** argv) {
     CK(hipGetDeviceProperties(&prop, 0));
     printf("device: %s  CUs=%d  %s  abi=%d\n", prop.name, prop.multiProcessorCount, mg_version(), mg_abi_version());
     if (argc > 1 && !strcmp(argv[1], "attn")) {  // quick perf loop on the dominant kernel
-        for (int variant = 0; variant < 2; ++variant) {
+        for (int variant = 0; variant < 4; ++variant) {
             printf("== attention variant %d ==\n", variant);
             mg_attn_set_variant(variant);
             test_attn(300, 300, 2, 0, false, 1);
@@ -459,11 +464,42 @@ int main(int argc, char** argv) {
         printf("%s: %d failure(s)\n", n_fail ? "SELFTEST FAILED" : "SELFTEST OK", n_fail);
         return n_fail ? 1 : 0;
     }
+    if (argc > 1 && !strcmp(argv[1], "w64dbg")) {  // pipelined pass only (flagged blocks are NOT redone)
+        mg_attn_set_variant(3);
+        mg_attn_w64_debug(argc > 2 ? atoi(argv[2]) : 1);
+        test_attn(300, 300, 2, 0, false, 1);
+        if (argc > 3) return 0;
+        test_attn(300, 256, 2, 0, false, 1);
+        test_attn(300, 192, 1, 0, false, 1);
+        test_attn(300, 320, 1, 0, false, 1);
+        test_attn(300, 257, 1, 0, false, 1);
+        test_attn(700, 512, 3, 0, false, 1);
+        test_attn(75600, 75600, 8, 24, true, 1);
+        test_attn(75600, 75584, 8, 24, true, 1);
+        return 0;
+    }
+    if (argc > 1 && !strcmp(argv[1], "w64prof")) {  // s_memtime breakdown of the w64 hot loop
+        unsigned long long* buf;
+        CK(hipMalloc(&buf, 16 * 8));
+        CK(hipMemset(buf, 0, 16 * 8));
+        mg_attn_set_variant(3);
+        mg_attn_w64_profile(buf);
+        test_attn(75600, 75584, 8, 8, true, 1);
+        unsigned long long h[16];
+        CK(hipMemcpy(h, buf, sizeof h, hipMemcpyDeviceToHost));
+        for (int w = 0; w < 4; ++w) {
+            const double n = (double)h[w * 4 + 3];
+            printf("wave %d: iterations %.0f  fence %.0f  step A %.0f  step B %.0f  (cycles per tile, 64 MFMAs)\n", w, n, h[w * 4] / n,
+                   h[w * 4 + 1] / n, h[w * 4 + 2] / n);
+        }
+        mg_attn_w64_profile(nullptr);
+        return 0;
+    }
     if (argc > 1 && !strcmp(argv[1], "attnprof")) {  // s_memtime breakdown of schedule 5's hot loop
         unsigned long long* buf;
         CK(hipMalloc(&buf, 40 * 8));
         CK(hipMemset(buf, 0, 40 * 8));
-        mg_attn_set_variant(argc > 2 ? atoi(argv[2]) : 0);
+        mg_attn_set_variant(argc > 2 ? atoi(argv[2]) : 1);
         mg_attn_debug_profile(buf);
         test_attn(75600, 75600, 8, 8, true, 1);
         unsigned long long h[40];

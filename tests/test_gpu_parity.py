@@ -174,9 +174,11 @@ def test_attention_vs_oracle(dev, Lq, Lk, heads, hd, attn_variant):
         assert scale_err(out2[0], ref2) < 2e-2
 
 
-def test_attention_rescale_branch(dev, attn_variant):
+@pytest.mark.parametrize('spikes', [(4, 6), (9, 14)], ids=['2^65_2^98', '2^147_2^229'])
+def test_attention_rescale_branch(dev, attn_variant, spikes):
     """force the online-softmax rescale (a key tile whose scores dwarf the earlier ones) and check
-    lazy (defer-max) == eager rescaling (cdna guide §5.4 rule 26)."""
+    lazy (defer-max) == eager rescaling (cdna guide §5.4 rule 26).  The second pair overflows fp32
+    relative to the first keys: the w64 kernel must take its exact second pass."""
     from oracle import dit
     from wan.backend import lib
     from wan.modules.attention import flash_attention
@@ -184,8 +186,8 @@ def test_attention_rescale_branch(dev, attn_variant):
     q = (W.randn((1, Lq, 1, 128), 14)).bfloat16()
     k = (W.randn((1, Lk, 1, 128), 15) * 0.2).bfloat16()
     v = W.randn((1, Lk, 1, 128), 16).bfloat16()
-    k[0, 300] = (q[0, 7] * 4).clone()          # tile 4 spikes for query 7
-    k[0, 500] = (q[0, 100] * 6).clone()        # tile 7 spikes for query 100
+    k[0, 300] = (q[0, 7] * spikes[0]).clone()          # tile 4 spikes for query 7
+    k[0, 500] = (q[0, 100] * spikes[1]).clone()        # tile 7 spikes for query 100
     ref = dit.attention(q[0].float(), k[0].float(), v[0].float(), Lk, True)
     outs = []
     for lazy in (0, 1):
@@ -196,9 +198,9 @@ def test_attention_rescale_branch(dev, attn_variant):
     assert scale_err(outs[0], outs[1]) < 2e-2
 
 
-@pytest.fixture(params=[0, 1], ids=['hipcc_reads', 'asm_ring'])
+@pytest.fixture(params=[0, 1, 2, 3], ids=['auto', 'two_level', 'two_level_asm_ring', 'w64'])
 def attn_variant(request):
-    """run a test under both fragment-read flavours of mg_attn_fwd_bf16_hd128."""
+    """run a test under every kernel selection of mg_attn_fwd_bf16_hd128."""
     from wan.backend import lib
     lib.load().mg_attn_set_variant(request.param)
     yield request.param
@@ -377,7 +379,7 @@ def test_pipeline_cfg1(dev, golden, solver):
 # ------------------------------------------------------------------------------------------------
 # size-independent properties at BASELINE.json configs[1] sizes (L = 75 600, 40 heads, d = 5120)
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('variant', [0, 1])
+@pytest.mark.parametrize('variant', [1, 2, 3])
 def test_fullsize_attention_properties(dev, variant):
     """both schedules (lock-step, ping-pong) of the MFMA attention kernel at the full 720p size."""
     from wan.backend import lib, ops
