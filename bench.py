@@ -204,7 +204,7 @@ def main():
             'sec_per_video_50steps_dit_only': ms_step * 50 / 1e3,
             'model_tflops_per_gpu': 2 * fl_fwd / (elapsed / args.steps) / world / 1e12,
             'mfma_frac_whole_step': 2 * fl_fwd / (elapsed / args.steps) / world / PEAK_BF16,
-            'roofline': {'kernel': 'attn_fwd_hd128_kernel (self-attention)', 'bound': 'mfma',
+            'roofline': {'kernel': 'attn_hd128_w64_kernel (self-attention, mg_attn_fwd_bf16_hd128)', 'bound': 'mfma',
                          'achieved': ach, 'peak': PEAK_BF16 / 1e12, 'unit': 'TFLOP/s',
                          'frac': (ach * 1e12 / PEAK_BF16) if ach else None, 'traffic': None,
                          'launches_timed': len(attn_events), 'ms_per_launch': attn_ms,

@@ -64,6 +64,63 @@ __global__ __launch_bounds__(WAVES * 64, 2) void probe(const u32x4_t* __restrict
     if (tid == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void probe_stage(const u32x4_t* __restrict__ in, float* __restrict__ out, int iters,
+                                                      unsigned long long* __restrict__ cyc) {
+    __shared__ __attribute__((aligned(16))) char smem[96 * 1024];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 4096; i += 256) ((u32x4_t*)smem)[i] = in[i];
+    __syncthreads();
+    bf16x8_t a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a[i] = __builtin_bit_cast(bf16x8_t, in[(tid * 4 + i) & 4095]);
+        b[i] = __builtin_bit_cast(bf16x8_t, in[(tid * 4 + i + 1777) & 4095]);
+    }
+    f32x16_t acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    float x[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x[i] = 0.001f * (lane + i);
+    const float c = 0.999f;
+    const char* lp = smem + lane * 16;
+    const u32x4_t* gsrc = in + ((blockIdx.x * 64 + lane) & 2047);
+    char* ldst = smem + 65536 + wave * 4096;
+    u32x4_t stage = {0, 0, 0, 0};
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            acc[j & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j & 3], b[(j >> 2) & 3], acc[j & 3], 0, 0, 0);
+            a[(j + 3) & 3] = *(const bf16x8_t*)(lp + ((j * 1024 + it * 16384) & 0xfc00));
+#pragma unroll
+            for (int f = 0; f < 4; ++f) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(x[f]) : "v"(c));
+            if (MODE == 1 && (j & 7) == 3)
+                __builtin_amdgcn_global_load_lds((gptr_t)(gsrc + ((it * 2 + (j >> 3)) & 31) * 64), (lptr_t)(ldst + (j >> 3) * 1024), 16, 0, 0);
+            if (MODE == 2 && (j & 7) == 3) stage = gsrc[((it * 2 + (j >> 3)) & 31) * 64];
+            if (MODE == 2 && (j & 7) == 7) *(u32x4_t*)(ldst + (j >> 3) * 1024 + lane * 16) = stage;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float r = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) r += acc[i][e];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r += x[i];
+    r += smem[65536 + tid];
+    out[blockIdx.x * 256 + tid] = r;
+    if (tid == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
 template <int NACC, int FILL, int TRANS, int LDSR, int WAVES, int LDSKB = 64>
@@ -90,21 +147,46 @@ void run(const u32x4_t* in, float* out, unsigned long long* cyc, int zero) {
            LDSR, LDSKB > 64 ? WAVES : 2 * WAVES > 8 ? 8 : 2 * WAVES, zero ? "zeros " : "random", flops / (ms * 1e-3) / 1e12, cs / (iters * 16.0), ms);
 }
 
+template <int MODE>
+void run_stage(const u32x4_t* in, float* out, unsigned long long* cyc) {
+    const int iters = 20000, grid = 256 * 4;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL((probe_stage<MODE>), dim3(grid), dim3(256), 0, 0, in, out, 2000, cyc);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL((probe_stage<MODE>), dim3(grid), dim3(256), 0, 0, in, out, iters, cyc);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<unsigned long long> h(grid);
+    CK(hipMemcpy(h.data(), cyc, grid * 8, hipMemcpyDeviceToHost));
+    double cs = 0;
+    for (auto v : h) cs += (double)v;
+    cs /= grid;
+    printf("stage mode %d (0 none, 1 LDS-DMA, 2 global_load+ds_write; 1 KiB per 8 MFMAs): %8.1f TF/s  %6.1f cyc/MFMA  -> %.0f cyc per staged KiB\n",
+           MODE, (double)grid * 4 * iters * 16 * 32768.0 / (ms * 1e-3) / 1e12, cs / (iters * 16.0), MODE ? 0.0 : 0.0);
+}
+
 int main() {
     u32x4_t* in; float* out; unsigned long long* cyc;
     CK(hipMalloc(&in, 65536)); CK(hipMalloc(&out, 1024 * 512 * 4)); CK(hipMalloc(&cyc, 1024 * 8));
     std::vector<unsigned short> h(32768);
     for (int z = 0; z < 2; ++z) {
         srand(1);
+        if (z == 1) break;
         for (auto& v : h) {
             float f = z ? 0.f : ((rand() % 2001) - 1000) / 1000.0f;
             unsigned u; memcpy(&u, &f, 4);
             v = (unsigned short)(u >> 16);
         }
         CK(hipMemcpy(in, h.data(), 65536, hipMemcpyHostToDevice));
-        run<4, 0, 0, 0, 8>(in, out, cyc, z);
-        run<4, 0, 0, 0, 4>(in, out, cyc, z);
-        if (z) break;
+        CK(hipMemcpy(in, h.data(), 65536, hipMemcpyHostToDevice));
+        run_stage<0>(in, out, cyc);
+        run_stage<1>(in, out, cyc);
+        run_stage<2>(in, out, cyc);
+        break;
         run<1, 0, 0, 0, 8>(in, out, cyc, z);
         run<2, 0, 0, 0, 8>(in, out, cyc, z);
         run<4, 0, 0, 1, 8>(in, out, cyc, z);

@@ -157,12 +157,25 @@ MG_DEV void w64_step(W64State& s, const bf16x8_t (&qf)[2][8], bf16x8_t (&kf)[4],
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int r = i & 3, r2 = (i + 2) & 3;
-        // ---- K fragment i -> S^T (both query blocks); refill the ring slot two groups ahead ----
-        w64_wait<3>();                         // younger than K(i): V(i), K(i+1), V(i+1)
+        // Group i: K fragment i and V fragment i, four MFMAs S0 | PV0 | S1 | PV1 with the fillers between.
+        // The asm (S^T) and builtin (P.V) MFMAs alternate on purpose: hipcc cannot see into the asm, so
+        // a v_exp result consumed right behind an asm MFMA costs an s_nop; pair_a (ends with the exps)
+        // always sits in front of a builtin MFMA, pair_b (adds, cvt) in front of an asm one.
+        w64_wait<2>();                         // K(i) and V(i) landed; younger: K(i+1), V(i+1)
         __builtin_amdgcn_sched_barrier(0);
         if (SMODE == 1 && i == 0) w64_mfma_s0(s.st[KB][0], kf[r], qf[0][i]);
         else if (SMODE == 2 && i == 0) w64_mfma_s_after_valu(s.st[KB][0], kf[r], qf[0][i]);
         else if (SMODE != 0) w64_mfma_s(s.st[KB][0], kf[r], qf[0][i]);
+        __builtin_amdgcn_sched_barrier(0);
+        pair_a(i, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (PV) s.ot[i & 3][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[r], s.pf[KB][0][i >> 2], s.ot[i & 3][0], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        pair_b(i, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (SMODE == 1 && i == 0) w64_mfma_s0(s.st[KB][1], kf[r], qf[1][i]);
+        else if (SMODE == 2 && i == 0) w64_mfma_s_after_valu(s.st[KB][1], kf[r], qf[1][i]);
+        else if (SMODE != 0) w64_mfma_s(s.st[KB][1], kf[r], qf[1][i]);
         __builtin_amdgcn_sched_barrier(0);
         // A ds_read whose result nobody uses would leave its destination VGPR free for the compiler
         // to reuse while the data is still on its way (it lands ~100 cycles later and clobbers the new
@@ -180,18 +193,6 @@ MG_DEV void w64_step(W64State& s, const bf16x8_t (&qf)[2][8], bf16x8_t (&kf)[4],
             }
         } else if (i == 6) w64_rd<w64_koff(0)>(kf[r2], nk);
         else w64_rd<w64_koff(1)>(kf[r2], nk);
-        pair_a(i, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (SMODE == 1 && i == 0) w64_mfma_s0(s.st[KB][1], kf[r], qf[1][i]);
-        else if (SMODE == 2 && i == 0) w64_mfma_s_after_valu(s.st[KB][1], kf[r], qf[1][i]);
-        else if (SMODE != 0) w64_mfma_s(s.st[KB][1], kf[r], qf[1][i]);
-        __builtin_amdgcn_sched_barrier(0);
-        pair_b(i, 0);
-        // ---- V fragment i -> O^T (both query blocks) ----
-        w64_wait<3>();                         // younger than V(i): K(i+1), V(i+1), K(i+2)
-        __builtin_amdgcn_sched_barrier(0);
-        if (PV) s.ot[i & 3][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[r], s.pf[KB][0][i >> 2], s.ot[i & 3][0], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
         pair_a(i, 1);
         dma(i);
         __builtin_amdgcn_sched_barrier(0);
@@ -227,7 +228,7 @@ struct W64NoDma {
     __device__ __forceinline__ void operator()(int) const {}
 };
 
-template <int DUMMY>
+template <bool PROF>
 __global__ __launch_bounds__(W64_THREADS, 1) void attn_hd128_w64_kernel(
     const uint16_t* __restrict__ q, int64_t ldq, const uint16_t* __restrict__ kp, const uint16_t* __restrict__ vp,
     uint16_t* __restrict__ o, int64_t ldo, int64_t Lq, int64_t Lk, int heads, float c_log2, int nqb, int dbg, unsigned long long* __restrict__ prof) {
@@ -350,27 +351,27 @@ __global__ __launch_bounds__(W64_THREADS, 1) void attn_hd128_w64_kernel(
         // hot loop: tile t+1 must be full for step 2t+1, and K(t+2) is prefetched for the step after
         unsigned long long pf_fence = 0, pf_a = 0, pf_b = 0, pf_n = 0;
         for (; t + 1 < nfull; ++t) {
-            const unsigned long long c0 = prof ? __builtin_amdgcn_s_memtime() : 0;
+            const unsigned long long c0 = PROF ? __builtin_amdgcn_s_memtime() : 0;
             fence();                    // K(t+1), V(t) visible; everyone is past iteration t-1
-            const unsigned long long c1 = prof ? __builtin_amdgcn_s_memtime() : 0;
+            const unsigned long long c1 = PROF ? __builtin_amdgcn_s_memtime() : 0;
             // u = 2t: S(t,1) [K slot s1] | P.V(t-1,1) [V slot s0] | softmax S(t,0); refill K(t+2) -> slot s0
             w64_step<1, 1, true, true>(s, qf, kf, vf, k_addr(s1, 1), v_addr(s0, 1), k_addr(s2, 0), v_addr(s1, 0), c_log2,
                                        [&](int n) __attribute__((always_inline)) {   // all 8 refill pieces here:
                                            if (n < 4) dma_k(t + 2, s0, n);            // K(t+2) -> slot of tile t-1,
                                            else dma_v(t + 1, s2, n - 4);              // V(t+1) -> slot of tile t-2;
                                        });                                            // step B gives them time to land
-            const unsigned long long c2 = prof ? __builtin_amdgcn_s_memtime() : 0;
+            const unsigned long long c2 = PROF ? __builtin_amdgcn_s_memtime() : 0;
             // u = 2t+1: S(t+1,0) [K slot s2] | P.V(t,0) [V slot s1] | softmax S(t,1); refill V(t+1) -> slot s2
             w64_step<0, 1, true, true>(s, qf, kf, vf, k_addr(s2, 0), v_addr(s1, 0), k_addr(s2, 1), v_addr(s1, 1), c_log2,
                                        W64NoDma());
-            if (prof) {
+            if (PROF) {
                 const unsigned long long c3 = __builtin_amdgcn_s_memtime();
                 pf_fence += c1 - c0, pf_a += c2 - c1, pf_b += c3 - c2, pf_n += 1;
             }
             const int tmp = s0;
             s0 = s1, s1 = s2, s2 = tmp;
         }
-        if (prof && lane == 0) {
+        if (PROF && prof && lane == 0) {
             atomicAdd(prof + wave * 4 + 0, pf_fence);
             atomicAdd(prof + wave * 4 + 1, pf_a);
             atomicAdd(prof + wave * 4 + 2, pf_b);
@@ -453,7 +454,11 @@ extern "C" void mg_attn_w64_debug(int flags) { g_w64_dbg = flags; }   // debug h
 
 int mg_attn_w64_launch(const uint16_t* q, int64_t ldq, const uint16_t* kp, const uint16_t* vp, uint16_t* o, int64_t ldo,
                        int64_t Lq, int64_t Lk, int heads, float c_log2, int nqb, hipStream_t st) {
-    hipLaunchKernelGGL((attn_hd128_w64_kernel<0>), dim3((unsigned)(nqb * heads)), dim3(W64_THREADS), 0, st, q, ldq, kp, vp, o,
-                       ldo, Lq, Lk, heads, c_log2, nqb, g_w64_dbg, g_w64_prof);
+    if (g_w64_prof)
+        hipLaunchKernelGGL((attn_hd128_w64_kernel<true>), dim3((unsigned)(nqb * heads)), dim3(W64_THREADS), 0, st, q, ldq, kp, vp,
+                           o, ldo, Lq, Lk, heads, c_log2, nqb, g_w64_dbg, g_w64_prof);
+    else
+        hipLaunchKernelGGL((attn_hd128_w64_kernel<false>), dim3((unsigned)(nqb * heads)), dim3(W64_THREADS), 0, st, q, ldq, kp,
+                           vp, o, ldo, Lq, Lk, heads, c_log2, nqb, g_w64_dbg, nullptr);
     return mg_check_launch();
 }

@@ -22,14 +22,14 @@ def main():
         lines.append(f'{short(name):70s} {calls:7d} {tot:14.1f} {avg:12.1f} {pct:7.2f}')
     # split the attention kernel into self-attention (long) and cross-attention (512 keys) launches
     try:
-        q = ("select (end-start)/1000.0 from kernels where name like '%attn_fwd_hd128_kernel%'")
+        q = ("select (end-start)/1000.0 from kernels where name like '%attn_hd128%'")
         d = [r[0] for r in cur.execute(q)]
         big = [x for x in d if x > 10000]
         small = [x for x in d if x <= 10000]
         if big:
-            lines.append(f'# attn_fwd_hd128_kernel self-attention launches : n={len(big)} avg_us={sum(big)/len(big):.1f}')
+            lines.append(f'# mg_attn_fwd_bf16_hd128 self-attention launches (attn_hd128_w64_kernel) : n={len(big)} avg_us={sum(big)/len(big):.1f}')
         if small:
-            lines.append(f'# attn_fwd_hd128_kernel cross-attention launches: n={len(small)} avg_us={sum(small)/len(small):.1f}')
+            lines.append(f'# mg_attn_fwd_bf16_hd128 cross-attention launches (attn_hd128_kernel)    : n={len(small)} avg_us={sum(small)/len(small):.1f}')
     except sqlite3.Error as e:  # schema differences between rocprofv3 versions
         lines.append(f'# (per-launch split unavailable: {e})')
     text = '\n'.join(lines) + '\n'

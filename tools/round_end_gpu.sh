@@ -22,5 +22,27 @@ for tag, name in (('fetch', 'FETCH_SIZE'), ('write', 'WRITE_SIZE')):
         for kn, (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:12]:
             o.write(f'{name} {kn:42s} dispatches={n:5d} mean_KiB={v/n:.4e} total_KiB={v:.4e}\n')
 PY
+python3 tools/rocprof_summary.py $(ls gpurun_out/${TAG}_prof/*/*_results.db gpurun_out/${TAG}_prof/*_results.db 2>/dev/null | head -1) gpurun_out/${TAG}_bench720p_kernel_stats.txt > /dev/null 2>&1
+python3 - <<PY
+# HBM-side traffic of the dominant kernel (self-attention = every dispatch of attn_hd128_w64_kernel), per launch
+import csv, glob, json
+def mean_kib(tag):
+    v = []
+    for f in glob.glob('gpurun_out/${TAG}_pmc_%s/**/*counter_collection.csv' % tag, recursive=True):
+        for r in csv.DictReader(open(f)):
+            if 'attn_hd128_w64_kernel' in r['Kernel_Name']:
+                v.append(float(r['Counter_Value']))
+    return (sum(v) / len(v), len(v)) if v else (None, 0)
+fe, nf = mean_kib('fetch'); wr, nw = mean_kib('write')
+if fe is not None and wr is not None:
+    out = {'kernel': 'attn_hd128_w64_kernel, self-attention Lq=Lk=75600, 40 heads (bench.py 720p workload)',
+           'method': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, two separate passes of bench.py --steps 1 --warmup 0 (tools/round_end_gpu.sh); mean over the dispatches of the kernel',
+           'dispatches': [nf, nw], 'fetch_size_kib_per_launch_raw': fe, 'write_size_kib_per_launch_raw': wr,
+           'gfx950_correction': 'FETCH_SIZE reports 1/2 of the bytes of a wide coalesced read stream (MI355X_MICROARCH.md, HBM section): doubled; WRITE_SIZE as is',
+           'traffic_bytes_per_launch': 2 * fe * 1024 + wr * 1024,
+           'algorithmic_bytes_per_launch': 4 * 75600 * 5120 * 2}
+    json.dump(out, open('gpurun_out/${TAG}_pmc_traffic.json', 'w'), indent=1)
+    print(json.dumps(out))
+PY
 rm -rf gpurun_out/${TAG}_pmc_fetch gpurun_out/${TAG}_pmc_write   # keep only the summaries (size cap)
 tail -4 gpurun_out/${TAG}_pytest_gpu.log; tail -2 gpurun_out/${TAG}_smoke.log; tail -1 gpurun_out/${TAG}_bench720p.log; cat gpurun_out/${TAG}_pmc_fetch_summary.txt gpurun_out/${TAG}_pmc_write_summary.txt
