@@ -484,7 +484,7 @@ int main(int argc, char** argv) {
         CK(hipMemset(buf, 0, 16 * 8));
         mg_attn_set_variant(3);
         mg_attn_w64_profile(buf);
-        test_attn(75600, 75584, 8, 8, true, 1);
+        test_attn(75600, argc > 2 ? atoll(argv[2]) : 75584, argc > 3 ? atoi(argv[3]) : 8, 8, true, 1);
         unsigned long long h[16];
         CK(hipMemcpy(h, buf, sizeof h, hipMemcpyDeviceToHost));
         for (int w = 0; w < 4; ++w) {
