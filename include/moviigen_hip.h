@@ -95,10 +95,11 @@ int mg_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw,
                  const float* bias, int64_t M, int N, int K, int epilogue, void* out,
                  int64_t ldo, const float* gate, void* stream);
 
-/* Tile schedule of mg_gemm_bf16: 3 (default) = 256x256x64 tile, 8 waves, 2 LDS stages, LDS-DMA
- * pieces spread between the MFMAs (M > 256 and N > 128, else falls to 2); 2 = 256x128x64 tile,
- * 8 waves, 3-stage LDS ring with counted vmcnt (M > 128, else 1); 1 = 128x128x64 tile, 4 waves,
- * 2 stages.  Same results bit for bit. */
+/* Tile schedule of mg_gemm_bf16 (same results bit for bit):
+ * 5 (default) = 256x256x64 tile, 4 waves = ONE per SIMD (128x128 each, accumulators in AGPRs), 2 LDS
+ *     stages, LDS-DMA pieces and fragment reads spread between the MFMAs (M > 256 and N > 128, else 2);
+ * 3 = 256x256x64 tile, 8 waves (128x64 each); 2 = 256x128x64 tile, 8 waves, 3-stage LDS ring with
+ *     counted vmcnt (M > 128, else 1); 1 = 128x128x64 tile, 4 waves, 2 stages. */
 void mg_gemm_set_variant(int variant);
 
 /* softmax(q k^T * scale) v, non-causal, keys >= Lk masked; bf16 in/out, fp32 accumulate,

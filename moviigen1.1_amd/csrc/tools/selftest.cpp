@@ -15,6 +15,7 @@ extern "C" void mg_gemm_debug_profile(unsigned long long* dev_buf);
 extern "C" void mg_attn_w64_debug(int flags);
 extern "C" void mg_attn_w64_profile(unsigned long long* dev_buf);
 extern "C" void mg_gemm3_debug_profile(unsigned long long* dev_buf);
+extern "C" void mg_gemm5_debug_profile(unsigned long long* dev_buf);
 
 #define CK(x)                                                                      \
     do {                                                                           \
@@ -523,7 +524,7 @@ int main(int argc, char** argv) {
         CK(hipMemset(buf, 0, 32 * 8));
         const int gv = argc > 2 ? atoi(argv[2]) : 2;
         mg_gemm_set_variant(gv);
-        if (gv == 3) mg_gemm3_debug_profile(buf); else mg_gemm_debug_profile(buf);
+        if (gv == 5) mg_gemm5_debug_profile(buf); else if (gv == 3) mg_gemm3_debug_profile(buf); else mg_gemm_debug_profile(buf);
         test_gemm(75600, 5120, 5120, 0, 64, true);
         unsigned long long h[32];
         CK(hipMemcpy(h, buf, sizeof h, hipMemcpyDeviceToHost));
@@ -534,6 +535,7 @@ int main(int argc, char** argv) {
         }
         mg_gemm_debug_profile(nullptr);
         mg_gemm3_debug_profile(nullptr);
+        mg_gemm5_debug_profile(nullptr);
         return 0;
     }
     if (argc > 1 && !strcmp(argv[1], "gemm1")) {
@@ -541,7 +543,7 @@ int main(int argc, char** argv) {
         return n_fail ? 1 : 0;
     }
     if (argc > 1 && !strcmp(argv[1], "gemm")) {
-        for (int variant = 1; variant <= 3; ++variant) {
+        for (int variant : {1, 2, 3, 5}) {
             printf("== gemm variant %d ==\n", variant);
             mg_gemm_set_variant(variant);
             for (int epi = 0; epi < 4; ++epi) test_gemm(300, 256, 128, epi, 0, false);

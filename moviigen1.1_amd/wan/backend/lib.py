@@ -72,6 +72,10 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.argtypes = args
         fn.restype = _RESTYPE.get(name, ctypes.c_int)
+    # A/B switches for measurements (tools/): kernel selections of the GEMM and the attention
+    for env, fn in (('MOVIIGEN_GEMM_VARIANT', 'mg_gemm_set_variant'), ('MOVIIGEN_ATTN_VARIANT', 'mg_attn_set_variant')):
+        if os.environ.get(env):
+            getattr(lib, fn)(int(os.environ[env]))
     _lib = lib
     return lib
 
