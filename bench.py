@@ -97,6 +97,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--workload', default='720p', choices=sorted(WORKLOADS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-cfg-parallel', action='store_true',
+                    help='N > 1: Ulysses over all N ranks (the reference layout) instead of cond/uncond halves x Ulysses N/2')
     ap.add_argument('--layers', type=int, default=None, help='debug only: fewer layers (marks the line invalid)')
     args = ap.parse_args()
 
@@ -126,9 +128,17 @@ def main():
     model = wan.modules.WanModel(**cfg, device=dev)
     model.init_weights(seed=0)
     model.eval().requires_grad_(False)
+    cfgp = None
     if world > 1:
-        from wan.distributed.xdit_context_parallel import enable_sequence_parallel
-        enable_sequence_parallel(model)
+        # even N: cond / uncond halves, Ulysses inside each half (same math, less traffic: see
+        # wan/distributed/cfg_parallel.py); odd N or --no-cfg-parallel: Ulysses over all ranks
+        if world % 2 == 0 and not args.no_cfg_parallel:
+            from wan.distributed.cfg_parallel import enable_cfg_parallel
+            cfgp = enable_cfg_parallel(model)
+        else:
+            from wan.distributed.xdit_context_parallel import enable_sequence_parallel
+            enable_sequence_parallel(model)
+    sp = model.sp_size
     g = torch.Generator(device=dev).manual_seed(42)
     latent = torch.randn(*lat_shape, dtype=torch.float32, device=dev, generator=g)
     ctx = torch.randn(512, 4096, device=dev, generator=g).bfloat16()
@@ -160,8 +170,12 @@ def main():
     def step(i):
         nonlocal latent
         t = ts[i:i + 1]
-        cond = model([latent], t=t, context=[ctx], seq_len=L)[0]
-        uncond = model([latent], t=t, context=[ctx_null], seq_len=L)[0]
+        if cfgp is None:
+            cond = model([latent], t=t, context=[ctx], seq_len=L)[0]
+            uncond = model([latent], t=t, context=[ctx_null], seq_len=L)[0]
+        else:
+            mine = model([latent], t=t, context=[ctx_null if cfgp.branch else ctx], seq_len=L)[0]
+            cond, uncond = cfgp.exchange(mine)
         ops.cfg_combine(noise_pred, uncond, cond, 5.0)
         latent = sch.step(noise_pred.unsqueeze(0), ts_host[i], latent.unsqueeze(0), return_dict=False)[0].squeeze(0)
 
@@ -191,7 +205,7 @@ def main():
         ms_step = elapsed / args.steps * 1e3
         fl_fwd = flops_per_forward(L, cfg)
         attn_ms = sum(a.elapsed_time(b) for a, b in attn_events) / max(1, len(attn_events))
-        heads_loc = cfg['num_heads'] // world
+        heads_loc = cfg['num_heads'] // sp
         attn_flops = 4.0 * L * L * 128 * heads_loc
         ach = attn_flops / (attn_ms * 1e-3) / 1e12 if attn_events else None
         line = {
@@ -199,7 +213,7 @@ def main():
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_step, 'higher_is_better': True,
             'scaling': 'strong', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
             'config': {'workload': desc, 'latent': list(lat_shape), 'tokens': L, 'layers': cfg['num_layers'],
-                       'parallelism': f'ulysses_sp{world}' if world > 1 else 'single', 'solver': 'unipc',
+                       'parallelism': ('single' if world == 1 else f'cfg2 x ulysses_sp{sp}' if cfgp is not None else f'ulysses_sp{sp}'), 'solver': 'unipc',
                        'guide_scale': 5.0, 'weights': 'random N(0,0.02) bf16, seed 0'},
             'sec_per_video_50steps_dit_only': ms_step * 50 / 1e3,
             'model_tflops_per_gpu': 2 * fl_fwd / (elapsed / args.steps) / world / 1e12,

@@ -1,0 +1,50 @@
+"""CFG-parallel groups (a design option the reference does not have:
+its two classifier-free-guidance forwards run back to back on every rank, text2video.py:240-243).
+
+With an even number of ranks the world is split in two halves: ranks [0, P/2) evaluate the
+conditional forward, ranks [P/2, P) the unconditional one, each half running Ulysses sequence
+parallelism over P/2 ranks (none when P == 2).  After the forwards rank i and rank i + P/2 exchange
+their noise predictions (one all_gather of the latent, 19 MB at 720p) and every rank applies the
+guidance + scheduler update redundantly, so the latents stay replicated without a broadcast.
+
+Per rank and denoising step this is ONE forward over L/(P/2) tokens instead of TWO over L/P: the
+same FLOPs and 14 % fewer all-to-all bytes at P = 8, no all-to-all at all at P = 2, twice the GEMM
+row count per launch — and bit-identical results (each forward is the same computation as before)."""
+import torch
+import torch.distributed as dist
+
+from .xdit_context_parallel import enable_sequence_parallel
+
+
+class CfgParallel:
+    def __init__(self, branch, pair_group, sp_group, sp_size):
+        self.branch, self.pair_group, self.sp_group, self.sp_size = branch, pair_group, sp_group, sp_size
+
+    def exchange(self, mine):
+        """mine: this half's prediction (cond on branch 0, uncond on branch 1) -> (cond, uncond)."""
+        both = torch.empty(2, *mine.shape, dtype=mine.dtype, device=mine.device)
+        if dist.get_backend(self.pair_group) == 'gloo':   # tests: no _allgather_base, device tensors via the host
+            parts = [torch.empty(mine.shape, dtype=mine.dtype) for _ in range(2)]
+            dist.all_gather(parts, mine.cpu().contiguous(), group=self.pair_group)
+            both.copy_(torch.stack(parts))
+        else:
+            dist.all_gather_into_tensor(both, mine.contiguous(), group=self.pair_group)
+        return both[0], both[1]
+
+
+def enable_cfg_parallel(model):
+    """split WORLD into a conditional and an unconditional half; returns a CfgParallel, or None when
+    the world size is 1 or odd (the caller then runs both forwards itself)."""
+    if not dist.is_initialized():
+        return None
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if world < 2 or world % 2:
+        return None
+    half = world // 2
+    # every rank creates every group, in the same order (torch.distributed contract)
+    sp_groups = [dist.new_group(list(range(b * half, (b + 1) * half))) for b in range(2)]
+    pair_groups = [dist.new_group([i, i + half]) for i in range(half)]
+    branch = rank // half
+    if half > 1:
+        enable_sequence_parallel(model, group=sp_groups[branch])
+    return CfgParallel(branch, pair_groups[rank % half], sp_groups[branch], half)

@@ -30,7 +30,7 @@ from .utils.fm_solvers_unipc import FlowUniPCMultistepScheduler
 class WanT2V:
 
     def __init__(self, config, checkpoint_dir, device_id=0, rank=0, t5_fsdp=False, dit_fsdp=False, use_usp=False,
-                 t5_cpu=False, text_encoder=None, model=None, vae=None):
+                 t5_cpu=False, text_encoder=None, model=None, vae=None, cfg_parallel=False):
         self.device = torch.device(f'cuda:{device_id}')
         self.config = config
         self.rank = rank
@@ -60,12 +60,15 @@ class WanT2V:
         if dist.is_initialized():
             dist.barrier()
         self.model.to(self.device)
-        if use_usp:
+        self.cfgp = None
+        if use_usp and cfg_parallel:
+            # cond / uncond halves, Ulysses inside each half (wan/distributed/cfg_parallel.py)
+            from .distributed.cfg_parallel import enable_cfg_parallel
+            self.cfgp = enable_cfg_parallel(self.model)
+        if use_usp and self.cfgp is None:
             from .distributed.xdit_context_parallel import enable_sequence_parallel
             enable_sequence_parallel(self.model)
-            self.sp_size = self.model.sp_size
-        else:
-            self.sp_size = 1
+        self.sp_size = self.model.sp_size if use_usp else 1
         if dit_fsdp:
             from .distributed.fsdp import shard_model
             self.model = shard_model(self.model, device_id=device_id)
@@ -124,8 +127,13 @@ class WanT2V:
             noise_pred = torch.empty_like(latent)
             for i, t_host in enumerate(timesteps_host):
                 t = timesteps[i:i + 1]
-                cond = self.model([latent], t=t, context=context, seq_len=seq_len)[0]
-                uncond = self.model([latent], t=t, context=context_null, seq_len=seq_len)[0]
+                if self.cfgp is None:
+                    cond = self.model([latent], t=t, context=context, seq_len=seq_len)[0]
+                    uncond = self.model([latent], t=t, context=context_null, seq_len=seq_len)[0]
+                else:   # this half's branch only, then swap predictions with the partner rank
+                    mine = self.model([latent], t=t, context=context_null if self.cfgp.branch else context,
+                                      seq_len=seq_len)[0]
+                    cond, uncond = self.cfgp.exchange(mine)
                 ops.cfg_combine(noise_pred, uncond, cond, guide_scale)
                 latent = sample_scheduler.step(noise_pred.unsqueeze(0), t_host, latent.unsqueeze(0),
                                                return_dict=False, generator=seed_g)[0].squeeze(0)

@@ -38,6 +38,20 @@ gath = ulysses.all_gather_seq(full[rank], dist.group.WORLD, P)
 assert torch.equal(gath, torch.cat(full, 0)), 'all_gather_seq'
 print(f'ULYSSES_OK rank{rank}', flush=True)
 
+# ---- CFG-parallel groups: 2 ranks = cond | uncond, no Ulysses inside the halves -----------------------
+from wan.distributed.cfg_parallel import enable_cfg_parallel  # noqa: E402
+
+
+class _NoModel:
+    sp_size = 1
+
+
+cp = enable_cfg_parallel(_NoModel())
+assert cp is not None and cp.branch == rank and cp.sp_size == 1
+c, u = cp.exchange(torch.full((2, 3), float(rank + 1)))
+assert torch.equal(c, torch.full((2, 3), 1.0)) and torch.equal(u, torch.full((2, 3), 2.0))
+print(f'CFGP_HOST_OK rank{rank}', flush=True)
+
 # ---- block-sharded weights: every rank keeps 1/P, fetch(i) reassembles block i exactly -------------
 cfg = dict(W.TINY_DIT, num_layers=3)
 Pm = W.make_dit_params(cfg, 0)

@@ -154,3 +154,4 @@ def test_ulysses_gloo_world2():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert 'ULYSSES_OK rank0' in r.stdout and 'ULYSSES_OK rank1' in r.stdout
     assert 'SHARDS_OK rank0' in r.stdout and 'SHARDS_OK rank1' in r.stdout
+    assert 'CFGP_HOST_OK rank0' in r.stdout and 'CFGP_HOST_OK rank1' in r.stdout
