@@ -58,3 +58,24 @@ def all_gather_seq(x, group, P):
     else:
         dist.all_gather_into_tensor(out, x.contiguous(), group=group)
     return out
+
+
+def p2p_send(x, dst, group=None):
+    """activation of a pipeline cut -> rank dst: a 4-int64 shape header, then the fp32 payload."""
+    hdr = torch.tensor(list(x.shape) + [0] * (4 - x.dim()), dtype=torch.int64)
+    if dist.get_backend(group) == 'gloo':            # tests: device tensors are staged through the host
+        dist.send(hdr, dst, group=group)
+        dist.send(x.detach().cpu().contiguous(), dst, group=group)
+    else:
+        dist.send(hdr.to(x.device), dst, group=group)
+        dist.send(x.contiguous(), dst, group=group)
+
+
+def p2p_recv(src, device, group=None):
+    gloo = dist.get_backend(group) == 'gloo'
+    hdr = torch.empty(4, dtype=torch.int64, device='cpu' if gloo else device)
+    dist.recv(hdr, src, group=group)
+    shape = [int(v) for v in hdr.tolist() if v > 0]
+    x = torch.empty(*shape, dtype=torch.float32, device='cpu' if gloo else device)
+    dist.recv(x, src, group=group)
+    return x.to(device)

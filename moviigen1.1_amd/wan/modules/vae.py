@@ -128,16 +128,57 @@ class WanVAE_:
                 x = ops.vae_time_interleave(y, self._new(2 * T, H, W, C2 // 2))
         return self._conv(pre + 'resample.1', x, up2=True)
 
-    def _decoder_chunk(self, x, cache):
-        idx = [0]
-        x = self._cached_conv('decoder.conv1', x, cache, idx)
-        x = self._res('decoder.middle.0.', x, cache, idx)
-        x = self._attn('decoder.middle.1.', x)
-        x = self._res('decoder.middle.2.', x, cache, idx)
+    # ---- the decoder as a list of stages (each owns a contiguous range of feat_cache slots) ---------
+    def _stages(self):
+        """[(kind, prefix, cache slots used)] in execution order (reference Decoder3d.forward, vae.py:423-472)."""
+        st = [('conv1', 'decoder.conv1', 1), ('res', 'decoder.middle.0.', 2), ('attn', 'decoder.middle.1.', 0),
+              ('res', 'decoder.middle.2.', 2)]
         for kind, pre in self.layout:
-            x = self._res(pre, x, cache, idx) if kind == 'res' else self._up(pre, x, cache, idx)
+            st.append((kind, pre, 2 if kind == 'res' else (1 if (pre + 'time_conv.weight') in self.P else 0)))
+        st.append(('head', 'decoder.head.', 1))
+        return st
+
+    def _run_stage(self, stage, x, cache, idx):
+        kind, pre, _ = stage
+        if kind == 'conv1':
+            return self._cached_conv(pre, x, cache, idx)
+        if kind == 'res':
+            return self._res(pre, x, cache, idx)
+        if kind == 'attn':
+            return self._attn(pre, x)
+        if kind == 'up':
+            return self._up(pre, x, cache, idx)
         x = self._norm_silu(x, 'decoder.head.0.gamma')
         return self._cached_conv('decoder.head.2', x, cache, idx)
+
+    def _decoder_chunk(self, x, cache, first=0, last=None):
+        """stages [first, last) on one chunk; `cache` is the full feat_cache list (a rank only ever
+        touches the slots of its own stages)."""
+        stages = self._stages()
+        idx = [sum(s[2] for s in stages[:first])]
+        for stage in stages[first:len(stages) if last is None else last]:
+            x = self._run_stage(stage, x, cache, idx)
+        return x
+
+    def stage_costs(self, h, w):
+        """MACs per steady-state chunk (one latent frame) of every stage at latent size h x w — the
+        weights of the layer-pipelined multi-GPU decode."""
+        costs, frames, px = [], 1, h * w
+        for kind, pre, _ in self._stages():
+            names = [k for k in self.P if k.startswith(pre) and k.endswith('weight') and self.P[k].dim() == 5]
+            c = 0
+            for k in names:
+                scale = 4 if 'resample' in k else 1                  # the 2x nearest upsample is folded into this conv
+                f = 2 * frames if ('resample' in k and (pre + 'time_conv.weight') in self.P) else frames
+                c += self.P[k].numel() * px * scale * f
+            if kind == 'attn':
+                c += 2 * px * px * self.P[pre + 'proj.weight'].shape[0]
+            costs.append(c)
+            if kind == 'up':
+                px *= 4
+                if (pre + 'time_conv.weight') in self.P:
+                    frames *= 2
+        return costs
 
     @torch.no_grad()
     def decode(self, z, chunks=None):
@@ -159,6 +200,70 @@ class WanVAE_:
             f0 += y.shape[0]
         assert f0 == video.shape[1]
         return video
+
+    @torch.no_grad()
+    def decode_pipelined(self, z, group=None):
+        """Multi-GPU decode: the stage list is cut into world_size contiguous
+        segments of about equal cost; segment s runs on rank P-1-s, so rank 0 owns the head and
+        assembles the video.  Chunks (latent frames) flow through the ranks as a pipeline — the causal
+        feat_cache of a conv stays on the rank that owns the conv, only the activation of the cut
+        crosses ranks (one send/recv per chunk and cut).  Exactly the single-GPU arithmetic.
+        Every rank passes the same latent; returns the video on rank 0, None elsewhere."""
+        import torch.distributed as dist
+        from ..distributed.ulysses import p2p_recv, p2p_send
+        P, rank = dist.get_world_size(group), dist.get_rank(group)
+        if P == 1:
+            return self.decode(z)
+        z = z.to(self.device, torch.float32).contiguous()
+        C, T, H, W = z.shape
+        stages = self._stages()
+        cuts = partition_costs(self.stage_costs(H, W), min(P, len(stages)))
+        nseg = len(cuts) - 1
+        if rank >= nseg:                                   # more ranks than stages: the rest idle
+            return None
+        seg = nseg - 1 - rank                              # rank 0 owns the last segment (head + video)
+        first, last = cuts[seg], cuts[seg + 1]
+        src = dist.get_global_rank(group, rank + 1) if group is not None else rank + 1      # upstream: segment seg-1
+        dst = dist.get_global_rank(group, rank - 1) if group is not None else rank - 1      # downstream: segment seg+1
+        cache = [None] * (self.n_slots + 8)
+        video = self._new(3, 1 + 4 * (T - 1), 8 * H, 8 * W) if seg == nseg - 1 else None
+        if first == 0:
+            x_all = self._conv('conv2', ops.vae_latent_in(z, self.mean, self.inv_std, self._new(T, H, W, C)))
+        f0 = 0
+        for i in range(T):
+            x = x_all[i:i + 1] if first == 0 else p2p_recv(src, self.device, group)
+            y = self._decoder_chunk(x, cache, first, last)
+            if video is None:
+                p2p_send(y, dst, group)
+            else:
+                ops.vae_video_out(y, video, f0)
+                f0 += y.shape[0]
+        return video
+
+
+def partition_costs(costs, parts):
+    """cut points [0, ..., len(costs)] of `parts` contiguous non-empty segments minimising the largest
+    segment sum (exact DP; a dozen stages)."""
+    n = len(costs)
+    parts = max(1, min(parts, n))
+    pre = [0]
+    for c in costs:
+        pre.append(pre[-1] + c)
+    INF = float('inf')
+    best = [[INF] * (n + 1) for _ in range(parts + 1)]
+    arg = [[0] * (n + 1) for _ in range(parts + 1)]
+    best[0][0] = 0
+    for p in range(1, parts + 1):
+        for j in range(p, n + 1):
+            for k in range(p - 1, j):
+                v = max(best[p - 1][k], pre[j] - pre[k])
+                if v < best[p][j]:
+                    best[p][j], arg[p][j] = v, k
+    cuts, j = [n], n
+    for p in range(parts, 0, -1):
+        j = arg[p][j]
+        cuts.append(j)
+    return cuts[::-1]
 
 
 class WanVAE:
@@ -182,3 +287,7 @@ class WanVAE:
 
     def decode(self, zs):
         return [self.model.decode(u) for u in zs]
+
+    def decode_pipelined(self, zs, group=None):
+        """multi-GPU decode: every rank calls it with the same latents; videos on rank 0, None elsewhere."""
+        return [self.model.decode_pipelined(u, group) for u in zs]

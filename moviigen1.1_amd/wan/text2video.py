@@ -30,7 +30,7 @@ from .utils.fm_solvers_unipc import FlowUniPCMultistepScheduler
 class WanT2V:
 
     def __init__(self, config, checkpoint_dir, device_id=0, rank=0, t5_fsdp=False, dit_fsdp=False, use_usp=False,
-                 t5_cpu=False, text_encoder=None, model=None, vae=None, cfg_parallel=False):
+                 t5_cpu=False, text_encoder=None, model=None, vae=None, cfg_parallel=False, vae_parallel=False):
         self.device = torch.device(f'cuda:{device_id}')
         self.config = config
         self.rank = rank
@@ -61,6 +61,7 @@ class WanT2V:
             dist.barrier()
         self.model.to(self.device)
         self.cfgp = None
+        self.vae_parallel = bool(vae_parallel) and dist.is_initialized() and dist.get_world_size() > 1
         if use_usp and cfg_parallel:
             # cond / uncond halves, Ulysses inside each half (wan/distributed/cfg_parallel.py)
             from .distributed.cfg_parallel import enable_cfg_parallel
@@ -143,7 +144,11 @@ class WanT2V:
             if offload_model:
                 self.model.cpu()
                 torch.cuda.empty_cache()
-            videos = self.vae.decode(x0) if self.rank == 0 else None
+            if self.vae_parallel:    # layer-pipelined decode over all ranks, video assembled on rank 0
+                videos = self.vae.decode_pipelined(x0)
+                videos = videos if self.rank == 0 else None
+            else:
+                videos = self.vae.decode(x0) if self.rank == 0 else None
 
         del noise, latent, sample_scheduler
         if offload_model:

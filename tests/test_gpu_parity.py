@@ -470,6 +470,21 @@ def test_cfg_parallel_one_gpu(world):
         assert f'CFGP_OK rank{k}/{world}' in r.stdout
 
 
+@pytest.mark.parametrize('world', [2, 3])
+def test_vae_pipelined_one_gpu(world):
+    """layer-pipelined multi-rank VAE decode == single-GPU decode, bit for bit (video on rank 0)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={world}',
+                        '--master-addr', '127.0.0.1', '--master-port', str(29570 + world),
+                        os.path.join(root, 'tests', 'dist_vae_worker.py')], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    for k in range(world):
+        assert f'VAEPIPE_OK rank{k}/{world}' in r.stdout
+
+
 def test_rccl_backend_single_rank():
     """the production transport: backend "nccl" (RCCL) with device tensors, world_size 1 — the same
     collective calls and the Ulysses / sharded-weights branches of the forward, equal to the plain one."""

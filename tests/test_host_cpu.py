@@ -155,3 +155,12 @@ def test_ulysses_gloo_world2():
     assert 'ULYSSES_OK rank0' in r.stdout and 'ULYSSES_OK rank1' in r.stdout
     assert 'SHARDS_OK rank0' in r.stdout and 'SHARDS_OK rank1' in r.stdout
     assert 'CFGP_HOST_OK rank0' in r.stdout and 'CFGP_HOST_OK rank1' in r.stdout
+
+
+def test_vae_stage_partition():
+    """cut points of the layer-pipelined VAE decode: contiguous, non-empty, minimal bottleneck."""
+    from wan.modules.vae import partition_costs
+    assert partition_costs([5, 1, 1, 1, 9, 2, 2, 8], 3) == [0, 4, 6, 8]
+    assert partition_costs([1, 2, 3], 5) == [0, 1, 2, 3]            # more ranks than stages
+    assert partition_costs([4, 4, 4, 4], 2) == [0, 2, 4]
+    assert partition_costs([7], 1) == [0, 1]
