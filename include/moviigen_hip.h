@@ -231,6 +231,11 @@ int mg_vae_latent_in_f32(const float* z, const float* mean, const float* inv_std
 int mg_vae_video_out_f32(const float* x, int C, int T, int H, int W, float* out, int t_off,
                          int T_total, void* stream);
 
+/* Decoded video [3][T][H][W] fp32 -> uint8 frames [T][H][W][3] as the reference's cache_video writes
+ * them (wan/utils/utils.py:39-47): clamp(lo,hi), (x-lo)/max(hi-lo,1e-5), *255, truncating cast. */
+int mg_video_to_u8(const float* video, int T, int H, int W, float lo, float hi, uint8_t* frames,
+                   void* stream);
+
 /* time_conv channel halves -> interleaved frames (vae.py:133-137):
  * x [T][H][W][2C] -> out [2T][H][W][C], frame 2t from channels [0,C), 2t+1 from [C,2C). */
 int mg_vae_time_interleave_f32(const float* x, int T, int64_t HW, int C, float* out, void* stream);

@@ -372,6 +372,36 @@ extern "C" int mg_vae_video_out_f32(const float* x, int C, int T, int H, int W, 
     return mg_check_launch();
 }
 
+// decoded video [3][T][H][W] fp32 -> uint8 frames [T][H][W][3], the arithmetic of the reference's
+// cache_video for one video (wan/utils/utils.py:39-47: clamp to the value range, torchvision
+// make_grid normalisation (x - lo) / max(hi - lo, 1e-5), * 255, truncating cast)
+__global__ void video_to_u8_kernel(const float* __restrict__ v, int T, int64_t hw, float lo, float hi,
+                                   uint8_t* __restrict__ out) {
+    const int64_t total = (int64_t)T * hw;
+    const float span = fmaxf(hi - lo, 1e-5f);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        uint8_t px[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float x = fminf(hi, fmaxf(lo, v[(int64_t)c * total + i]));
+            px[c] = (uint8_t)(int)(((x - lo) / span) * 255.f);
+        }
+        out[i * 3 + 0] = px[0];
+        out[i * 3 + 1] = px[1];
+        out[i * 3 + 2] = px[2];
+    }
+}
+
+extern "C" int mg_video_to_u8(const float* video, int T, int H, int W, float lo, float hi, uint8_t* frames, void* stream) {
+    if (!video || !frames) return MG_ERR_ARG;
+    if (T <= 0 || H <= 0 || W <= 0 || !(hi >= lo)) return MG_ERR_SHAPE;
+    const int64_t hw = (int64_t)H * W;
+    int64_t g = ((int64_t)T * hw + 255) / 256;
+    if (g > 16384) g = 16384;
+    hipLaunchKernelGGL(video_to_u8_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, video, T, hw, lo, hi, frames);
+    return mg_check_launch();
+}
+
 __global__ void time_interleave_kernel(const float* __restrict__ x, int T, int64_t hw, int C, float* __restrict__ out) {
     // x [T][hw][2C] -> out [2T][hw][C]: frame 2t <- channels [0,C), frame 2t+1 <- [C,2C)  (vae.py:133-137)
     const int64_t total = (int64_t)2 * T * hw * C;

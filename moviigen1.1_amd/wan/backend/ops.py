@@ -226,3 +226,14 @@ def vae_time_interleave(x, out):
     T, H, W, C2 = x.shape
     lib.call('mg_vae_time_interleave_f32', _p(x), T, H * W, C2 // 2, _p(out), _st())
     return out
+
+
+def video_to_u8(video, lo=-1.0, hi=1.0):
+    """[3,T,H,W] fp32 -> uint8 frames [T,H,W,3] (reference cache_video arithmetic)."""
+    _chk(video, torch.float32, 'video')
+    if video.dim() != 4 or video.shape[0] != 3 or not video.is_contiguous():
+        raise lib.MoviigenHipError('video must be a contiguous [3, T, H, W] tensor')
+    _, T, H, W = video.shape
+    out = torch.empty(T, H, W, 3, dtype=torch.uint8, device=video.device)
+    lib.call('mg_video_to_u8', _p(video), T, H, W, float(lo), float(hi), _p(out), _st())
+    return out

@@ -1,0 +1,73 @@
+"""Video write-out — the step after the path (reference wan/utils/utils.py:23-60 `cache_video`,
+called from scripts/inference/generate.py:300-313).
+
+The arithmetic (clamp, make_grid normalisation of ONE video, x255, truncating cast to uint8 frames
+[T,H,W,3]) runs on the GPU (mg_video_to_u8, bit-exact with the reference expression).  The container
+encode is host-side as in the reference: `imageio` (libx264) when it is installed; this image has
+neither imageio nor an encoder, so the frames are then written as a raw `.npy` next to the requested
+name instead of being dropped."""
+import binascii
+import os
+import os.path as osp
+
+import numpy as np
+import torch
+
+from ..backend import ops
+
+__all__ = ['cache_video', 'video_frames_uint8', 'str2bool']
+
+
+def rand_name(length=8, suffix=''):
+    name = binascii.b2a_hex(os.urandom(length)).decode('utf-8')
+    if suffix:
+        name += suffix if suffix.startswith('.') else '.' + suffix
+    return name
+
+
+def video_frames_uint8(tensor, value_range=(-1, 1)):
+    """[1,3,T,H,W] or [3,T,H,W] fp32 device tensor -> uint8 [T,H,W,3] device tensor."""
+    if tensor.dim() == 5:
+        if tensor.shape[0] != 1:
+            raise NotImplementedError('make_grid of several videos (nrow tiling) is not on the T2V path: one video per call')
+        tensor = tensor[0]
+    return ops.video_to_u8(tensor.to(torch.float32).contiguous(), min(value_range), max(value_range))
+
+
+def cache_video(tensor, save_file=None, fps=30, suffix='.mp4', nrow=8, normalize=True, value_range=(-1, 1), retry=5):
+    if not normalize:
+        raise NotImplementedError('the reference always calls cache_video with normalize=True')
+    cache_file = osp.join('/tmp', rand_name(suffix=suffix)) if save_file is None else save_file
+    frames = video_frames_uint8(tensor, value_range).cpu().numpy()
+    try:
+        import imageio
+    except ModuleNotFoundError:
+        path = osp.splitext(cache_file)[0] + '.npy'
+        np.save(path, frames)
+        print(f'cache_video: imageio is not installed, wrote the uint8 frames {frames.shape} to {path}', flush=True)
+        return path
+    error = None
+    for _ in range(retry):
+        try:
+            writer = imageio.get_writer(cache_file, fps=fps, codec='libx264', quality=8)
+            for frame in frames:
+                writer.append_data(frame)
+            writer.close()
+            return cache_file
+        except Exception as e:  # noqa: BLE001  (the reference retries on any writer error)
+            error = e
+    print(f'cache_video failed, error: {error}', flush=True)
+    return None
+
+
+def str2bool(v):
+    """argparse helper of the reference CLI (utils.py:100-118)."""
+    if isinstance(v, bool):
+        return v
+    lv = v.lower()
+    if lv in ('yes', 'true', 't', 'y', '1'):
+        return True
+    if lv in ('no', 'false', 'f', 'n', '0'):
+        return False
+    import argparse
+    raise argparse.ArgumentTypeError('Boolean value expected (True/False)')

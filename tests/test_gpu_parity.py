@@ -470,6 +470,21 @@ def test_cfg_parallel_one_gpu(world):
         assert f'CFGP_OK rank{k}/{world}' in r.stdout
 
 
+def test_video_write_out(dev, tmp_path):
+    """uint8 frames == the reference's cache_video arithmetic (utils.py:39-47), byte for byte."""
+    from wan.utils.utils import cache_video, video_frames_uint8
+    v = (W.randn((3, 5, 18, 34), 77) * 0.8)
+    v[0, 0, 0, :4] = torch.tensor([1.0, -1.0, 1.7, -3.0])
+    x = v.clamp(-1, 1)
+    x = (x - (-1)) / max(1 - (-1), 1e-5)                       # torchvision make_grid(normalize=True, value_range)
+    ref = (x.permute(1, 2, 3, 0) * 255).type(torch.uint8)
+    got = video_frames_uint8(v.to(dev)[None])
+    assert got.dtype == torch.uint8 and tuple(got.shape) == (5, 18, 34, 3)
+    assert torch.equal(got.cpu(), ref)
+    path = cache_video(v.to(dev)[None], save_file=str(tmp_path / 'out.mp4'))
+    assert path is not None and (path.endswith('.mp4') or (path.endswith('.npy') and np.array_equal(np.load(path), ref.numpy())))
+
+
 @pytest.mark.parametrize('world', [2, 3])
 def test_vae_pipelined_one_gpu(world):
     """layer-pipelined multi-rank VAE decode == single-GPU decode, bit for bit (video on rank 0)."""
