@@ -152,9 +152,12 @@ class WanModel(nn.Module):
         from safetensors import safe_open
         with open(os.path.join(checkpoint_dir, 'config.json')) as f:
             cfg = json.load(f)
-        keys = ('model_type', 'text_len', 'in_dim', 'dim', 'ffn_dim', 'freq_dim', 'out_dim', 'num_heads',
+        keys = ('model_type', 'text_len', 'in_dim', 'dim', 'ffn_dim', 'freq_dim', 'text_dim', 'out_dim', 'num_heads',
                 'num_layers', 'eps')
-        model = cls(**{k: cfg[k] for k in keys if k in cfg}, device=device)
+        kw = {k: cfg[k] for k in keys if k in cfg}
+        if 'patch_size' in cfg:
+            kw['patch_size'] = tuple(cfg['patch_size'])
+        model = cls(**kw, device=device)
         idx = os.path.join(checkpoint_dir, 'diffusion_pytorch_model.safetensors.index.json')
         if os.path.exists(idx):
             with open(idx) as f:

@@ -37,10 +37,8 @@ class WanT2V:
         self.t5_cpu = t5_cpu
         self.num_train_timesteps = config.num_train_timesteps
         self.param_dtype = config.param_dtype
-        if t5_fsdp:
-            raise NotImplementedError('t5_fsdp: the 9.4 GB bf16 encoder is replicated (288 GB HBM per GPU)')
-        if t5_cpu:
-            raise NotImplementedError('t5_cpu: the text encoder has no CPU path in this build')
+        if t5_fsdp or t5_cpu:   # both only trade memory for time in the reference; the outputs are the same
+            logging.info('t5_fsdp / t5_cpu: the 9.4 GB bf16 text encoder is kept whole on the GPU (288 GB HBM)')
         t5_path = os.path.join(checkpoint_dir, config.t5_checkpoint) if checkpoint_dir else None
         if text_encoder is None and t5_path and os.path.exists(t5_path):
             from .modules.t5 import T5EncoderModel

@@ -470,6 +470,50 @@ def test_cfg_parallel_one_gpu(world):
         assert f'CFGP_OK rank{k}/{world}' in r.stdout
 
 
+def test_launcher_end_to_end(dev, tmp_path):
+    """scripts/inference/generate.py on a tiny synthetic checkpoint directory (config.json + safetensors
+    DiT + VAE .pth, prompt embeddings from a file): same video as driving WanT2V by hand."""
+    import importlib.util
+    import json
+    import os
+    from safetensors.torch import save_file
+    import wan
+    from wan.configs import SIZE_CONFIGS, SUPPORTED_SIZES, WAN_CONFIGS, Config
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('mg_generate', os.path.join(root, 'scripts', 'inference', 'generate.py'))
+    gen = importlib.util.module_from_spec(spec)
+    ck = tmp_path / 'ckpt'
+    ck.mkdir()
+    cfg = W.TINY_DIT
+    json.dump({k: (list(v) if isinstance(v, tuple) else v) for k, v in cfg.items()}, open(ck / 'config.json', 'w'))
+    save_file({k: (v.bfloat16() if v.dim() >= 2 and 'modulation' not in k else v).contiguous()
+               for k, v in W.make_dit_params(cfg, 0).items()}, str(ck / 'diffusion_pytorch_model.safetensors'))
+    torch.save(W.make_vae_params(8, 1), ck / 'Wan2.1_VAE.pth')
+    torch.save({'prompt': W.randn((9, cfg['text_dim']), 50), 'negative': W.randn((5, cfg['text_dim']), 51)}, ck / 'emb.pt')
+    tiny = Config(WAN_CONFIGS['t2v-14B'])
+    tiny.update(text_len=cfg['text_len'], num_heads=cfg['num_heads'], sample_fps=16)
+    WAN_CONFIGS['t2v-tiny'], SIZE_CONFIGS['64*64'], SUPPORTED_SIZES['t2v-tiny'] = tiny, (64, 64), ('64*64',)
+    try:
+        spec.loader.exec_module(gen)
+        gen.EXAMPLE_PROMPT['t2v-tiny'] = {'prompt': 'x'}
+        out = tmp_path / 'clip.mp4'
+        args = gen.generate(gen._parse_args(['--task', 't2v-tiny', '--size', '64*64', '--frame_num', '5', '--ckpt_dir', str(ck),
+                                             '--sample_steps', '2', '--base_seed', '3', '--prompt_embeds', str(ck / 'emb.pt'),
+                                             '--save_file', str(out), '--offload_model', 'False']))
+        assert args.saved_as is not None and os.path.exists(args.saved_as)
+        pipe = wan.WanT2V(tiny, str(ck), device_id=0)
+        emb = torch.load(ck / 'emb.pt')
+        video = pipe.generate(emb['prompt'], size=(64, 64), frame_num=5, shift=5.0, sampling_steps=2, guide_scale=5.0,
+                              n_prompt=emb['negative'], seed=3, offload_model=False)
+        assert tuple(video.shape) == (3, 5, 64, 64)
+        if args.saved_as.endswith('.npy'):
+            from wan.utils.utils import video_frames_uint8
+            assert np.array_equal(np.load(args.saved_as), video_frames_uint8(video[None]).cpu().numpy())
+    finally:
+        for d, k in ((WAN_CONFIGS, 't2v-tiny'), (SIZE_CONFIGS, '64*64'), (SUPPORTED_SIZES, 't2v-tiny')):
+            d.pop(k, None)
+
+
 def test_video_write_out(dev, tmp_path):
     """uint8 frames == the reference's cache_video arithmetic (utils.py:39-47), byte for byte."""
     from wan.utils.utils import cache_video, video_frames_uint8

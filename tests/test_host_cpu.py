@@ -164,3 +164,44 @@ def test_vae_stage_partition():
     assert partition_costs([1, 2, 3], 5) == [0, 1, 2, 3]            # more ranks than stages
     assert partition_costs([4, 4, 4, 4], 2) == [0, 2, 4]
     assert partition_costs([7], 1) == [0, 1]
+
+
+def _launcher():
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('mg_generate', os.path.join(root, 'scripts', 'inference', 'generate.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_launcher_flags_and_defaults():
+    """scripts/inference/generate.py keeps the reference CLI's flags, defaults and validation
+    (reference generate.py:36-179) and its output naming (:300-306)."""
+    import datetime
+    g = _launcher()
+    a = g._parse_args(['--ckpt_dir', '/x'])
+    assert (a.task, a.size, a.frame_num, a.sample_steps, a.sample_shift, a.sample_guide_scale) == \
+        ('t2v-14B', '1280*720', 81, 50, 5.0, 5.0)
+    assert (a.ulysses_size, a.ring_size, a.sample_solver, a.offload_model) == (1, 1, 'unipc', None)
+    assert not (a.t5_fsdp or a.t5_cpu or a.dit_fsdp or a.use_prompt_extend) and a.base_seed >= 0
+    assert g._parse_args(['--ckpt_dir', '/x', '--task', 't2i-14B']).frame_num == 1
+    b = g._parse_args(['--ckpt_dir', '/x', '--base_seed', '42', '--offload_model', 'False', '--sample_solver', 'dpm++',
+                       '--ulysses_size', '4', '--dit_fsdp', '--t5_fsdp', '--prompt', 'A cat walks on the grass/now'])
+    assert b.base_seed == 42 and b.offload_model is False and b.sample_solver == 'dpm++' and b.dit_fsdp and b.t5_fsdp
+    with pytest.raises(AssertionError, match='Please specify the checkpoint directory'):
+        g._parse_args([])
+    with pytest.raises(AssertionError, match='Unsupport size'):
+        g._parse_args(['--ckpt_dir', '/x', '--size', '1024*1024'])
+    with pytest.raises(AssertionError, match='Unsupport frame_num'):
+        g._parse_args(['--ckpt_dir', '/x', '--task', 't2i-14B', '--frame_num', '5'])
+    with pytest.raises(SystemExit):
+        g._parse_args(['--ckpt_dir', '/x', '--sample_solver', 'euler'])
+    name = g.default_save_name(b, datetime.datetime(2026, 1, 2, 3, 4, 5))
+    assert name == 't2v-14B_1280*720_4_1_A_cat_walks_on_the_grass_now_20260102_030405.mp4'
+    # single process: the reference's assertions on distributed-only flags
+    with pytest.raises(AssertionError, match='not supported in non-distributed'):
+        g.generate(g._parse_args(['--ckpt_dir', '/x', '--dit_fsdp']))
+    with pytest.raises(AssertionError, match='context parallel'):
+        g.generate(g._parse_args(['--ckpt_dir', '/x', '--ulysses_size', '2']))
