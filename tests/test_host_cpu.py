@@ -76,10 +76,8 @@ def test_state_dict_layout_and_from_pretrained(tmp_path):
     json.dump({k: cfg[k] for k in ('model_type', 'text_len', 'in_dim', 'dim', 'ffn_dim', 'freq_dim', 'out_dim',
                                    'num_heads', 'num_layers', 'eps')} | {'text_dim': cfg['text_dim']},
               open(tmp_path / 'config.json', 'w'))
-    # text_dim is in ignore_for_config in the reference; the tiny config needs it, 14B uses the default
-    m2 = wan.modules.WanModel.from_pretrained.__func__(
-        type('T', (wan.modules.WanModel,), {'__init__': lambda self, **kw: wan.modules.WanModel.__init__(
-            self, text_dim=cfg['text_dim'], **kw)}), str(tmp_path))
+    # text_dim is not in the reference's config.json (14B uses the default 4096); from_pretrained honours it when present
+    m2 = wan.modules.WanModel.from_pretrained(str(tmp_path))
     sd = m2.state_dict()
     for k in keys:
         ref = P[k].to(sd[k].dtype)
