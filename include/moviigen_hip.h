@@ -115,6 +115,20 @@ int mg_attn_fwd_bf16_hd128(const uint16_t* q, int64_t ldq, const uint16_t* kp, c
 /* Same contract for any head_dim <= 256 (head_dim % 8 == 0): the correctness path for model
  * sizes whose head_dim is not 128 (BASELINE.json configs[0]: head_dim 32).  v is NOT transposed:
  * v [Lk][>=heads*head_dim] row stride ldv. */
+/* Same, plus the log-sum-exp of the scaled scores per (head, query): lse[head*Lq + q] fp32 (may be
+ * NULL = mg_attn_fwd_bf16_hd128).  Ring attention merges per-block results with it. */
+int mg_attn_fwd_bf16_hd128_lse(const uint16_t* q, int64_t ldq, const uint16_t* kp, const uint16_t* vp,
+                               uint16_t* o, int64_t ldo, float* lse, int64_t Lq, int64_t Lk, int heads,
+                               float scale, void* stream);
+
+/* Ring attention (the reference delegates to yunchang inside xFuserLongContextAttention,
+ * generate.py:225-229): fold one block's normalised bf16 result `part` [Lq][heads*128] and its lse into
+ * the running fp32 result: lse' = logaddexp(lse, lse_j), acc' = acc*exp(lse-lse') + part*exp(lse_j-lse').
+ * first != 0 initialises acc/lse_acc from the block; out (bf16, may be NULL) receives acc'. */
+int mg_attn_merge_f32(float* acc, int64_t lda, float* lse_acc, const uint16_t* part, int64_t ldp,
+                      const float* lse_part, uint16_t* out, int64_t ldo, int64_t Lq, int heads, int first,
+                      void* stream);
+
 int mg_attn_fwd_bf16_generic(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk,
                              const uint16_t* v, int64_t ldv, uint16_t* o, int64_t ldo, int64_t Lq,
                              int64_t Lk, int heads, int head_dim, float scale, void* stream);

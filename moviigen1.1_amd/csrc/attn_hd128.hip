@@ -265,7 +265,7 @@ template <bool LAZY, int DEPTH, bool PROF = false, bool ASM = false>
 __global__ __launch_bounds__(ATT_THREADS, 2) void attn_hd128_kernel(
     const uint16_t* __restrict__ q, int64_t ldq, const uint16_t* __restrict__ kp, const uint16_t* __restrict__ vp,
     uint16_t* __restrict__ o, int64_t ldo, int64_t Lq, int64_t Lk, int heads, float c_log2, int nqb,
-    unsigned long long* __restrict__ prof) {
+    unsigned long long* __restrict__ prof, float* __restrict__ lse) {
     unsigned long long pt[5] = {0, 0, 0, 0, 0}, pc = 0;   // PROF: s_memtime sums of S^T / softmax / P.V / fence / fast tiles
     auto tick = [&](int i) __attribute__((always_inline)) {
         if (PROF) {
@@ -385,6 +385,8 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_hd128_kernel(
     }
     const float l_tot = s.l_run + __shfl_xor(s.l_run, 32, 64);
     const float inv = 1.f / l_tot;
+    // optional log-sum-exp of the scaled scores (ring attention merges partial results with it)
+    if (lse && g == 0 && qrow_raw < Lq) lse[(int64_t)head * Lq + qrow_raw] = (s.m_run * c_log2 + __log2f(l_tot)) * 0.6931471805599453f;
     if (qrow_raw < Lq) {
         uint16_t* op = o + qrow_raw * ldo + head * 128 + g * 4;
 #pragma unroll
@@ -455,15 +457,15 @@ static unsigned long long* g_attn_prof = nullptr;
 // debug hook (not in the public header): device buffer of 8 waves x 5 counters for schedule 5's PROF build
 extern "C" void mg_attn_debug_profile(unsigned long long* dev_buf) { g_attn_prof = dev_buf; }
 int mg_attn_w64_launch(const uint16_t* q, int64_t ldq, const uint16_t* kp, const uint16_t* vp, uint16_t* o, int64_t ldo,
-                       int64_t Lq, int64_t Lk, int heads, float c_log2, int nqb, hipStream_t st);
+                       int64_t Lq, int64_t Lk, int heads, float c_log2, int nqb, float* lse, hipStream_t st);
 static int g_attn_lazy = 1;
 static int g_attn_variant = 0;
 extern "C" void mg_attn_set_lazy_rescale(int on) { g_attn_lazy = on; }
 extern "C" void mg_attn_set_variant(int v) { g_attn_variant = v; }
 
-extern "C" int mg_attn_fwd_bf16_hd128(const uint16_t* q, int64_t ldq, const uint16_t* kp, const uint16_t* vp,
-                                      uint16_t* o, int64_t ldo, int64_t Lq, int64_t Lk, int heads, float scale,
-                                      void* stream) {
+extern "C" int mg_attn_fwd_bf16_hd128_lse(const uint16_t* q, int64_t ldq, const uint16_t* kp, const uint16_t* vp,
+                                          uint16_t* o, int64_t ldo, float* lse, int64_t Lq, int64_t Lk, int heads,
+                                          float scale, void* stream) {
     if (!q || !kp || !vp || !o) return MG_ERR_ARG;
     if (Lq < 0 || Lk <= 0 || heads <= 0) return MG_ERR_SHAPE;
     if ((ldq & 7) || (ldo & 3)) return MG_ERR_SHAPE;
@@ -478,9 +480,9 @@ extern "C" int mg_attn_fwd_bf16_hd128(const uint16_t* q, int64_t ldq, const uint
     // 0 = auto: the one-wave-per-SIMD "w64" kernel for long key sequences (self-attention), the
     // two-level lock-step kernel for short ones (cross-attention: 8 key tiles, prologue-dominated)
     const int variant = g_attn_variant == 0 ? (Lk >= 2048 ? 3 : 1) : g_attn_variant;
-    if (variant == 3) return mg_attn_w64_launch(q, ldq, kp, vp, o, ldo, Lq, Lk, heads, c_log2, nqb, st);
+    if (variant == 3) return mg_attn_w64_launch(q, ldq, kp, vp, o, ldo, Lq, Lk, heads, c_log2, nqb, lse, st);
 #define ATT_LAUNCH(LZ, DP, PROF, ASM) \
-    hipLaunchKernelGGL((attn_hd128_kernel<LZ, DP, PROF, ASM>), grid, block, 0, st, q, ldq, kp, vp, o, ldo, Lq, Lk, heads, c_log2, nqb, g_attn_prof)
+    hipLaunchKernelGGL((attn_hd128_kernel<LZ, DP, PROF, ASM>), grid, block, 0, st, q, ldq, kp, vp, o, ldo, Lq, Lk, heads, c_log2, nqb, g_attn_prof, lse)
     if (variant == 2) {
         if (g_attn_prof) ATT_LAUNCH(true, 8, true, true);
         else if (g_attn_lazy) ATT_LAUNCH(true, 8, false, true);
@@ -492,4 +494,10 @@ extern "C" int mg_attn_fwd_bf16_hd128(const uint16_t* q, int64_t ldq, const uint
     }
 #undef ATT_LAUNCH
     return mg_check_launch();
+}
+
+extern "C" int mg_attn_fwd_bf16_hd128(const uint16_t* q, int64_t ldq, const uint16_t* kp, const uint16_t* vp,
+                                      uint16_t* o, int64_t ldo, int64_t Lq, int64_t Lk, int heads, float scale,
+                                      void* stream) {
+    return mg_attn_fwd_bf16_hd128_lse(q, ldq, kp, vp, o, ldo, nullptr, Lq, Lk, heads, scale, stream);
 }

@@ -231,7 +231,7 @@ struct W64NoDma {
 template <bool PROF>
 __global__ __launch_bounds__(W64_THREADS, 1) void attn_hd128_w64_kernel(
     const uint16_t* __restrict__ q, int64_t ldq, const uint16_t* __restrict__ kp, const uint16_t* __restrict__ vp,
-    uint16_t* __restrict__ o, int64_t ldo, int64_t Lq, int64_t Lk, int heads, float c_log2, int nqb, int dbg, unsigned long long* __restrict__ prof) {
+    uint16_t* __restrict__ o, int64_t ldo, int64_t Lq, int64_t Lk, int heads, float c_log2, int nqb, int dbg, unsigned long long* __restrict__ prof, float* __restrict__ lse) {
     __shared__ __attribute__((aligned(16))) char smem[6 * W64_TILE];
     const int bid = blockIdx.x;
     const int tid = threadIdx.x;
@@ -476,6 +476,7 @@ __global__ __launch_bounds__(W64_THREADS, 1) void attn_hd128_w64_kernel(
         const float l_tot = s.l_run[b] + __shfl_xor(s.l_run[b], 32, 64);
         const float inv = 1.f / l_tot;
         const int64_t qr = (int64_t)qb0 * W64_QB + wave * 64 + l31 + b * 32;
+        if (lse && g == 0 && qr < Lq) lse[(int64_t)head * Lq + qr] = (s.m_run[b] * c_log2 + __log2f(l_tot)) * 0.6931471805599453f;
         if (qr < Lq) {
             uint16_t* op = o + qr * ldo + head * 128 + g * 4;
 #pragma unroll
@@ -498,7 +499,7 @@ extern "C" void mg_attn_w64_profile(unsigned long long* dev_buf) { g_w64_prof = 
 extern "C" void mg_attn_w64_debug(int flags) { g_w64_dbg = flags; }   // debug hook, not in the public header
 
 int mg_attn_w64_launch(const uint16_t* q, int64_t ldq, const uint16_t* kp, const uint16_t* vp, uint16_t* o, int64_t ldo,
-                       int64_t Lq, int64_t Lk, int heads, float c_log2, int nqb, hipStream_t st) {
+                       int64_t Lq, int64_t Lk, int heads, float c_log2, int nqb, float* lse, hipStream_t st) {
     static int n_cu = 0;
     if (!n_cu) {
         hipDeviceProp_t prop;
@@ -511,9 +512,9 @@ int mg_attn_w64_launch(const uint16_t* q, int64_t ldq, const uint16_t* kp, const
     const unsigned grid = total <= n_cu ? (unsigned)total : (unsigned)n_cu;   // persistent when there is more work than CUs
     if (g_w64_prof)
         hipLaunchKernelGGL((attn_hd128_w64_kernel<true>), dim3(grid), dim3(W64_THREADS), 0, st, q, ldq, kp, vp, o, ldo, Lq, Lk,
-                           heads, c_log2, nqb, g_w64_dbg, g_w64_prof);
+                           heads, c_log2, nqb, g_w64_dbg, g_w64_prof, lse);
     else
         hipLaunchKernelGGL((attn_hd128_w64_kernel<false>), dim3(grid), dim3(W64_THREADS), 0, st, q, ldq, kp, vp, o, ldo, Lq, Lk,
-                           heads, c_log2, nqb, g_w64_dbg, nullptr);
+                           heads, c_log2, nqb, g_w64_dbg, nullptr, lse);
     return mg_check_launch();
 }

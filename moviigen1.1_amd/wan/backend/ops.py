@@ -237,3 +237,25 @@ def video_to_u8(video, lo=-1.0, hi=1.0):
     out = torch.empty(T, H, W, 3, dtype=torch.uint8, device=video.device)
     lib.call('mg_video_to_u8', _p(video), T, H, W, float(lo), float(hi), _p(out), _st())
     return out
+
+
+def attention_hd128_lse(q, kp, vp, out, lse, lk, heads, scale):
+    """attention_hd128 that also writes lse [heads, Lq] fp32 (log-sum-exp of the scaled scores)."""
+    _chk(q, torch.bfloat16, 'q'); _chk(kp, torch.bfloat16, 'kp'); _chk(vp, torch.bfloat16, 'vp')
+    _chk(out, torch.bfloat16, 'out'); _chk(lse, torch.float32, 'lse')
+    if min(kp.numel(), vp.numel()) < packed_kv_numel(int(lk), int(heads)):
+        raise lib.MoviigenHipError('packed K/V buffers too small for lk keys')
+    if lse.numel() < int(heads) * q.shape[0] or not lse.is_contiguous():
+        raise lib.MoviigenHipError('lse must be a contiguous [heads, Lq] fp32 tensor')
+    lib.call('mg_attn_fwd_bf16_hd128_lse', _p(q), q.stride(0), _p(kp), _p(vp), _p(out), out.stride(0), _p(lse),
+             q.shape[0], int(lk), int(heads), float(scale), _st())
+    return out, lse
+
+
+def attention_merge(acc, lse_acc, part, lse_part, heads, first, out=None):
+    """ring attention: fold block result (part bf16, lse_part) into (acc fp32, lse_acc); out = bf16 copy of acc."""
+    _chk(acc, torch.float32, 'acc'); _chk(lse_acc, torch.float32, 'lse_acc'); _chk(part, torch.bfloat16, 'part')
+    _chk(lse_part, torch.float32, 'lse_part'); _chk(out, torch.bfloat16, 'out')
+    lib.call('mg_attn_merge_f32', _p(acc), acc.stride(0), _p(lse_acc), _p(part), part.stride(0), _p(lse_part), _p(out),
+             out.stride(0) if out is not None else 0, acc.shape[0], int(heads), int(bool(first)), _st())
+    return acc

@@ -1,0 +1,70 @@
+"""Ring attention over RCCL.  The reference gets it from yunchang inside
+xFuserLongContextAttention when `--ring_size > 1` (scripts/inference/generate.py:102-106,225-229);
+here it is the engine's second sequence-parallel layout next to Ulysses:
+
+  tokens are sharded as for Ulysses (rank r owns [r*L/P, (r+1)*L/P)), but every rank keeps ALL heads.
+  The packed K/V block of a rank travels round the ring (send to r+1, receive from r-1, P-1 hops,
+  overlapped with the attention of the block at hand on a second buffer); each hop's result
+  (normalised bf16 output + log-sum-exp, mg_attn_fwd_bf16_hd128_lse) is folded into an fp32 running
+  result (mg_attn_merge_f32).  No head-count divisibility requirement (Ulysses needs heads % P == 0).
+
+Not bit-identical to the single-GPU result (the merge rounds differently from one long softmax):
+tested to the bf16 tolerance."""
+import torch
+import torch.distributed as dist
+
+from ..backend import ops
+
+
+def enable_ring_attention(model, group=None):
+    """shard the token axis of `model` over `group` with ring attention instead of Ulysses."""
+    if not dist.is_initialized():
+        raise RuntimeError('torch.distributed is not initialised (launch with torchrun, one process per GPU)')
+    if model.dim // model.num_heads != 128:
+        raise NotImplementedError('ring attention is built on the head_dim 128 kernels')
+    model.sp_group = group if group is not None else dist.group.WORLD
+    model.sp_size = dist.get_world_size(group)
+    model.sp_rank = dist.get_rank(group)
+    model.ring = True
+    model._ws = {}
+    return model
+
+
+def _exchange(send_bufs, recv_bufs, group, P, rank):
+    """post the hop: send_bufs -> rank+1, recv_bufs <- rank-1; returns the requests to wait on."""
+    nxt = dist.get_global_rank(group, (rank + 1) % P) if group is not dist.group.WORLD else (rank + 1) % P
+    prv = dist.get_global_rank(group, (rank - 1) % P) if group is not dist.group.WORLD else (rank - 1) % P
+    if dist.get_backend(group) == 'gloo':      # tests: device tensors are staged through the host
+        host_s = [b.cpu() for b in send_bufs]
+        host_r = [torch.empty(b.shape, dtype=b.dtype) for b in recv_bufs]
+        reqs = [dist.P2POp(dist.isend, t, nxt, group) for t in host_s] + \
+               [dist.P2POp(dist.irecv, t, prv, group) for t in host_r]
+        works = dist.batch_isend_irecv(reqs)
+        return works, (host_r, recv_bufs)
+    reqs = [dist.P2POp(dist.isend, t, nxt, group) for t in send_bufs] + \
+           [dist.P2POp(dist.irecv, t, prv, group) for t in recv_bufs]
+    return dist.batch_isend_irecv(reqs), None
+
+
+def ring_attention(q, k, v, out, ws, group, P, rank, heads, scale):
+    """q, k, v [Lloc, heads*128] bf16 (row strides free), out [Lloc, heads*128] bf16.
+    ws: dict with packed buffers kp0/vp0/kp1/vp1, part (bf16 [Lloc, heads*128]), acc (fp32), lse, lse_acc."""
+    Lloc = q.shape[0]
+    cur, nxt = (ws['kp0'], ws['vp0']), (ws['kp1'], ws['vp1'])
+    ops.pack_kv(k, v, heads, cur[0], cur[1])
+    for j in range(P):
+        pending = None
+        if j + 1 < P:
+            pending = _exchange(list(cur), list(nxt), group, P, rank)
+        ops.attention_hd128_lse(q, cur[0], cur[1], ws['part'], ws['lse'], Lloc, heads, scale)
+        ops.attention_merge(ws['acc'], ws['lse_acc'], ws['part'], ws['lse'], heads, first=(j == 0),
+                            out=out if j == P - 1 else None)
+        if pending is not None:
+            works, staged = pending
+            for w in works:
+                w.wait()
+            if staged is not None:
+                for h, d in zip(*staged):
+                    d.copy_(h)
+            cur, nxt = nxt, cur
+    return out

@@ -139,6 +139,7 @@ class WanModel(nn.Module):
         # sequence-parallel placement, installed by wan.distributed (Ulysses); 1 = single GPU
         self.sp_size, self.sp_rank, self.sp_group = 1, 0, None
         self.sp_force = False   # run the Ulysses collectives even on a 1-rank group (RCCL smoke test)
+        self.ring = False       # sequence parallelism by ring attention instead of Ulysses (wan/distributed/ring.py)
         self._packed = None
         self._ws = {}
         self._rope = {}
@@ -272,10 +273,15 @@ class WanModel(nn.Module):
                       hf=e(L, d, dt=f32), y=e(L, math.prod(self.patch_size) * self.out_dim, dt=f32),
                       sin=e(1, self.freq_dim, dt=f32), e1=e(d, dt=f32), e=e(d, dt=f32), e0=e(6, d, dt=f32),
                       mod=e(6 * self.num_layers, d, dt=f32), hmod=e(2, d, dt=f32))
-            if hd == 128:   # K / V packed into 64-key tiles (operand layout of the MFMA attention kernel)
+            if hd == 128 and not (self.ring and self.sp_size > 1):   # K / V packed into 64-key tiles (operand layout of the MFMA attention kernel)
                 n_pk = ops.packed_kv_numel(Ltot, self.num_heads // self.sp_size)
                 ws['kp'], ws['vp'] = e(n_pk), e(n_pk)
-            if self.sp_size > 1 or self.sp_force:
+            if self.ring and self.sp_size > 1:
+                n1 = ops.packed_kv_numel(L, self.num_heads)
+                ws['kp0'], ws['vp0'], ws['kp1'], ws['vp1'] = e(n1), e(n1), e(n1), e(n1)
+                ws['part'], ws['acc'] = e(L, d), e(L, d, dt=f32)
+                ws['lse'], ws['lse_acc'] = e(self.num_heads, L, dt=f32), e(self.num_heads, L, dt=f32)
+            elif self.sp_size > 1 or self.sp_force:
                 n_loc = self.num_heads // self.sp_size
                 ws['qg'], ws['kg'], ws['vg'] = e(Ltot, n_loc * hd), e(Ltot, n_loc * hd), e(Ltot, n_loc * hd)
                 ws['ag'] = e(Ltot, n_loc * hd)
@@ -351,6 +357,11 @@ class WanModel(nn.Module):
             else:
                 self._attention(ws['q'], ws['k'], qkv[:, 2 * d:], ws['a'], self._kv_valid, N)
             return
+        if self.ring:
+            from ..distributed.ring import ring_attention
+            ring_attention(ws['q'], ws['k'], qkv[:, 2 * d:], ws['a'], ws, self.sp_group, self.sp_size, self.sp_rank, N,
+                           1.0 / math.sqrt(hd))
+            return
         from ..distributed import ulysses
         n_loc = N // self.sp_size
         ulysses.seq_to_head(ws['q'], ws['qg'], self.sp_group, self.sp_size, N, hd)
@@ -379,7 +390,7 @@ class WanModel(nn.Module):
         if P > 1:
             # reference SP path does not mask padded keys (xdit_context_parallel.py:178-193): it is
             # only correct without padding, which is what every supported size gives
-            assert seq_len == Lfull and Lfull % P == 0 and self.num_heads % P == 0, \
+            assert seq_len == Lfull and Lfull % P == 0 and (self.ring or self.num_heads % P == 0), \
                 'sequence parallel needs L % sp == 0, heads % sp == 0 and no padding'
         L = Lfull // P
         pos0 = self.sp_rank * L

@@ -544,6 +544,60 @@ def test_vae_pipelined_one_gpu(world):
         assert f'VAEPIPE_OK rank{k}/{world}' in r.stdout
 
 
+@pytest.mark.parametrize('world', [2, 3])
+def test_ring_attention_one_gpu(world):
+    """ring attention (operator and whole forward) vs one long softmax, head counts not divisible by the ring size."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={world}',
+                        '--master-addr', '127.0.0.1', '--master-port', str(29580 + world),
+                        os.path.join(root, 'tests', 'dist_ring_worker.py')], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    for k in range(world):
+        assert f'RING_OP_OK rank{k}/{world}' in r.stdout and f'RING_MODEL_OK rank{k}/{world}' in r.stdout
+
+
+def test_attention_lse_and_merge(dev):
+    """mg_attn_fwd_bf16_hd128_lse (both kernels) and mg_attn_merge_f32 against fp32 math on one GPU."""
+    from wan.backend import lib, ops
+    heads, Lq = 2, 300
+    for Lk in (200, 2300):                                   # two-level kernel / w64 kernel (Lk >= 2048)
+        q = (W.randn((Lq, heads * 128), 71) * 1.2).bfloat16().to(dev)
+        k = (W.randn((Lk, heads * 128), 72) * 1.2).bfloat16().to(dev)
+        v = W.randn((Lk, heads * 128), 73).bfloat16().to(dev)
+        n = ops.packed_kv_numel(Lk, heads)
+        kp, vp = torch.empty(n, dtype=torch.bfloat16, device=dev), torch.empty(n, dtype=torch.bfloat16, device=dev)
+        ops.pack_kv(k, v, heads, kp, vp)
+        out = torch.empty(Lq, heads * 128, dtype=torch.bfloat16, device=dev)
+        lse = torch.empty(heads, Lq, dtype=torch.float32, device=dev)
+        ops.attention_hd128_lse(q, kp, vp, out, lse, Lk, heads, 128 ** -0.5)
+        s = (q.float().view(Lq, heads, 128).permute(1, 0, 2) @ k.float().view(Lk, heads, 128).permute(1, 2, 0)) * 128 ** -0.5
+        assert (lse - torch.logsumexp(s, -1)).abs().max().item() < 2e-3, Lk
+        ref = (torch.softmax(s, -1) @ v.float().view(Lk, heads, 128).permute(1, 0, 2)).permute(1, 0, 2).reshape(Lq, -1)
+        assert scale_err(out.float(), ref) < 2e-2
+    # merge of two halves == the whole
+    h = Lk // 2 // 64 * 64
+    parts = []
+    for a, b in ((0, h), (h, Lk)):
+        n = ops.packed_kv_numel(b - a, heads)
+        kp, vp = torch.empty(n, dtype=torch.bfloat16, device=dev), torch.empty(n, dtype=torch.bfloat16, device=dev)
+        ops.pack_kv(k[a:b], v[a:b], heads, kp, vp)
+        o = torch.empty(Lq, heads * 128, dtype=torch.bfloat16, device=dev)
+        l = torch.empty(heads, Lq, dtype=torch.float32, device=dev)
+        ops.attention_hd128_lse(q, kp, vp, o, l, b - a, heads, 128 ** -0.5)
+        parts.append((o, l))
+    acc = torch.empty(Lq, heads * 128, dtype=torch.float32, device=dev)
+    lacc = torch.empty(heads, Lq, dtype=torch.float32, device=dev)
+    fin = torch.empty(Lq, heads * 128, dtype=torch.bfloat16, device=dev)
+    ops.attention_merge(acc, lacc, parts[0][0], parts[0][1], heads, True)
+    ops.attention_merge(acc, lacc, parts[1][0], parts[1][1], heads, False, out=fin)
+    assert scale_err(fin.float(), ref) < 2e-2 and (lacc - torch.logsumexp(s, -1)).abs().max().item() < 2e-3
+    with pytest.raises(lib.MoviigenHipError):
+        ops.attention_hd128_lse(q, kp, vp, out, torch.empty(3, dtype=torch.float32, device=dev), Lk, heads, 1.0)
+
+
 def test_rccl_backend_single_rank():
     """the production transport: backend "nccl" (RCCL) with device tensors, world_size 1 — the same
     collective calls and the Ulysses / sharded-weights branches of the forward, equal to the plain one."""
