@@ -20,6 +20,7 @@
 //  * workgroup ids are remapped so each XCD (private 4 MiB L2) walks a contiguous, 8-tile-tall
 //    band of the output: the concurrently resident tiles of one XCD share A and W panels.
 #include "common.h"
+#include "gemm_epilogue.h"
 #include "../../include/moviigen_hip.h"
 
 #define BM 128
@@ -129,75 +130,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(
         }
     }
 
-    // ---- epilogue: lane owns token row m, features n..n+3 per accumulator quad ---------------
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int64_t m = m0 + wm * 64 + j * 32 + l31;
-        if (m >= M) continue;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                const int n = n0 + wn * 64 + i * 32 + rq * 8 + g * 4;
-                if (n >= N) continue;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][rq * 4 + e];
-                const bool full = (n + 3 < N);
-                if (bias) {
-                    if (full) {
-                        const float4 b4 = *(const float4*)(bias + n);
-                        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (n + e < N) v[e] += bias[n + e];
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = round_bf(v[e]);  // nn.Linear output is bf16
-                if (EPI == MG_EPI_BIAS_GELU_BF16) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
-                }
-                if (EPI == MG_EPI_BIAS_BF16 || EPI == MG_EPI_BIAS_GELU_BF16) {
-                    uint16_t* o = (uint16_t*)out + m * ldo + n;
-                    if (full) {
-                        uint2 p;
-                        p.x = pack_bf2(v[0], v[1]);
-                        p.y = pack_bf2(v[2], v[3]);
-                        *(uint2*)o = p;
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (n + e < N) o[e] = f2bf(v[e]);
-                    }
-                } else {
-                    float* o = (float*)out + m * ldo + n;
-                    if (EPI == MG_EPI_GATE_RESID_F32) {
-                        if (full) {
-                            float4 gg = gate ? *(const float4*)(gate + n) : make_float4(1.f, 1.f, 1.f, 1.f);
-                            float4 x4 = *(float4*)o;
-                            x4.x += v[0] * gg.x; x4.y += v[1] * gg.y; x4.z += v[2] * gg.z; x4.w += v[3] * gg.w;
-                            *(float4*)o = x4;
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (n + e < N) o[e] += v[e] * (gate ? gate[n + e] : 1.f);
-                        }
-                    } else {
-                        if (full) {
-                            *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (n + e < N) o[e] = v[e];
-                        }
-                    }
-                }
-            }
-        }
-    }
+    // ---- epilogue (gemm_epilogue.h): lane owns token row m, 4 features per accumulator quad; batched loads ----
+    mg_gemm_epilogue<EPI, 2, 2>(acc, m0 + wm * 64, n0 + wn * 64, l31, g, M, N, bias, gate, out, ldo);
 }
 
 int mg_gemm_v5_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_t ldw, const float* bias, int64_t M,

@@ -3,6 +3,7 @@
 // its SIMD hides its fragment reads (8 ds_read_b128 per 16 MFMAs) behind its own MFMAs, and an
 // unguarded LDS-DMA piece costs it ~30 cycles instead of the 60-100 measured with two waves per SIMD.
 #include "common.h"
+#include "gemm_epilogue.h"
 #include "../../include/moviigen_hip.h"
 
 #define V5_BM 256
@@ -154,75 +155,8 @@ __global__ __launch_bounds__(V5_THREADS, 1) void gemm_bf16_v5_kernel(
         for (int i = 0; i < 4; ++i) atomicAdd(prof + wave * 4 + i, pt[i]);
     }
 
-    // ---- epilogue (identical to gemm_bf16.hip): lane owns token row m, 4 features per quad -----------
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int64_t m = m0 + wm * 128 + j * 32 + l31;
-        if (m >= M) continue;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                const int n = n0 + wn * 128 + i * 32 + rq * 8 + g * 4;
-                if (n >= N) continue;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][rq * 4 + e];
-                const bool full = (n + 3 < N);
-                if (bias) {
-                    if (full) {
-                        const float4 b4 = *(const float4*)(bias + n);
-                        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (n + e < N) v[e] += bias[n + e];
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = round_bf(v[e]);
-                if (EPI == MG_EPI_BIAS_GELU_BF16) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
-                }
-                if (EPI == MG_EPI_BIAS_BF16 || EPI == MG_EPI_BIAS_GELU_BF16) {
-                    uint16_t* o = (uint16_t*)out + m * ldo + n;
-                    if (full) {
-                        uint2 p;
-                        p.x = pack_bf2(v[0], v[1]);
-                        p.y = pack_bf2(v[2], v[3]);
-                        *(uint2*)o = p;
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (n + e < N) o[e] = f2bf(v[e]);
-                    }
-                } else {
-                    float* o = (float*)out + m * ldo + n;
-                    if (EPI == MG_EPI_GATE_RESID_F32) {
-                        if (full) {
-                            float4 gg = gate ? *(const float4*)(gate + n) : make_float4(1.f, 1.f, 1.f, 1.f);
-                            float4 x4 = *(float4*)o;
-                            x4.x += v[0] * gg.x; x4.y += v[1] * gg.y; x4.z += v[2] * gg.z; x4.w += v[3] * gg.w;
-                            *(float4*)o = x4;
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (n + e < N) o[e] += v[e] * (gate ? gate[n + e] : 1.f);
-                        }
-                    } else {
-                        if (full) {
-                            *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (n + e < N) o[e] = v[e];
-                        }
-                    }
-                }
-            }
-        }
-    }
+    // ---- epilogue (gemm_epilogue.h): lane owns token row m, 4 features per accumulator quad; batched loads ----
+    mg_gemm_epilogue<EPI, 4, 4>(acc, m0 + wm * 128, n0 + wn * 128, l31, g, M, N, bias, gate, out, ldo);
 }
 
 int mg_gemm_v5_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_t ldw, const float* bias, int64_t M,
