@@ -105,7 +105,12 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
+    if world > 1 and os.environ.get('MOVIIGEN_BENCH_BACKEND') == 'gloo':
+        # test plumbing only (tests/test_gpu_parity.py::test_bench_multirank_code_path): N ranks share cuda:0 and
+        # talk through gloo, so the N > 1 branches of this file run on a 1-GPU box.  Never a measurement.
+        local = 0
+        dist.init_process_group('gloo')
+    elif world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         torch.cuda.set_device(local)
         dist.init_process_group('nccl', device_id=torch.device(f'cuda:{local}'))
@@ -234,6 +239,8 @@ def main():
                     pmc = json.load(f)
                 line['roofline']['traffic'] = pmc.get('traffic_bytes_per_launch')
                 line['roofline']['traffic_unit'] = 'bytes/launch (FETCH_SIZE x2 + WRITE_SIZE, ' + os.path.basename(found[-1]) + ')'
+        if os.environ.get('MOVIIGEN_BENCH_BACKEND') == 'gloo':
+            line['invalid'] = 'gloo test transport on a shared GPU (code-path check, not a measurement)'
         if args.layers or args.workload == 'tiny':
             line['invalid'] = 'debug configuration (not the BASELINE model)'
         if world == 1 and not args.no_cpu_baseline:

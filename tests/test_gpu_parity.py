@@ -598,6 +598,32 @@ def test_attention_lse_and_merge(dev):
         ops.attention_hd128_lse(q, kp, vp, out, torch.empty(3, dtype=torch.float32, device=dev), Lk, heads, 1.0)
 
 
+@pytest.mark.parametrize('world,extra', [(2, []), (4, []), (2, ['--no-cfg-parallel'])])
+def test_bench_multirank_code_path(world, extra):
+    """bench.py's N > 1 branches (CFG-parallel halves x Ulysses, or Ulysses over all ranks) on one GPU through
+    gloo, tiny workload: must print ONE JSON line with the contract keys."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MOVIIGEN_BENCH_BACKEND='gloo')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={world}',
+                        '--master-addr', '127.0.0.1', '--master-port', str(29590 + world + len(extra)),
+                        os.path.join(root, 'bench.py'), '--gpus', str(world), '--steps', '1', '--warmup', '1',
+                        '--workload', 'tiny'] + extra, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+              'vs_baseline', 'dtype', 'data', 'config', 'roofline'):
+        assert k in d, k
+    assert d['n_gpus'] == world and d['scaling'] == 'strong' and d['value'] > 0
+    want = f'ulysses_sp{world}' if extra else (f'cfg2 x ulysses_sp{world // 2}')
+    assert d['config']['parallelism'] == want, d['config']
+
+
 def test_rccl_backend_single_rank():
     """the production transport: backend "nccl" (RCCL) with device tensors, world_size 1 — the same
     collective calls and the Ulysses / sharded-weights branches of the forward, equal to the plain one."""
