@@ -128,7 +128,11 @@ template <int KB, int SMODE, bool PV, bool SM, typename Dma>
 MG_DEV void w64_step(W64State& s, const bf16x8_t (&qf)[2][8], bf16x8_t (&kf)[4], bf16x8_t (&vf)[4], unsigned lds_k,
                      unsigned lds_v, unsigned nk, unsigned nv, float c_log2, Dma dma) {
     constexpr int SB = 1 - KB;          // unit being exponentiated
+#ifndef W64_PK_ADD
+#define W64_PK_ADD 0
+#endif
     float mc[2], psa[2] = {0.f, 0.f}, psb[2] = {0.f, 0.f};
+    f32x2_t ps2[2] = {{0.f, 0.f}, {0.f, 0.f}};
     u32x4_t w[2][2];
     if (SM) {
         mc[0] = s.m_run[0] * c_log2;
@@ -147,10 +151,18 @@ MG_DEV void w64_step(W64State& s, const bf16x8_t (&qf)[2][8], bf16x8_t (&kf)[4],
     auto pair_b = [&](int i, int half) __attribute__((always_inline)) {   // add, add, cvt_pk
         if (SM) {
             const int qb = i >> 2, j = (i & 3) * 2 + half;
+#if W64_PK_ADD
+            // both partial row sums in ONE packed add — measured 1117 instead of 1233 TFLOP/s: packed f32 VALU is an
+            // anti-lever beside MFMAs on gfx950 (MI355X_MICROARCH.md); kept as an experiment switch, default off
+            asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(ps2[qb]) : "v"(__builtin_shufflevector((f32x2_t){pa, pa}, (f32x2_t){pb, pb}, 0, 2)));
+            unsigned pk = pack_bf2(pa, pb);
+            asm volatile("" : "+v"(pk));
+#else
             psa[qb] += pa;
             psb[qb] += pb;
             unsigned pk = pack_bf2(pa, pb);
             asm volatile("" : "+v"(pk), "+v"(psa[qb]), "+v"(psb[qb]));
+#endif
             w[qb][j >> 2][j & 3] = pk;
         }
     };
@@ -215,7 +227,7 @@ MG_DEV void w64_step(W64State& s, const bf16x8_t (&qf)[2][8], bf16x8_t (&kf)[4],
     if (SM) {
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
-            const float psum = psa[qb] + psb[qb];
+            const float psum = W64_PK_ADD ? ps2[qb][0] + ps2[qb][1] : psa[qb] + psb[qb];
             s.bad |= !(psum <= 1.2676506e30f);  // 2^100; inf / NaN too
             s.l_run[qb] += psum;
             s.pf[SB][qb][0] = w64_bf(w[qb][0]);
