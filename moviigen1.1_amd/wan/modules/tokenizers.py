@@ -1,66 +1,70 @@
-"""HuggingfaceTokenizer — drop-in for reference wan/modules/tokenizers.py:50-82 (the prompt ->
-token ids step in front of the umT5 encoder).  `ftfy` (mojibake repair) is used when installed;
-without it the text passes through NFC normalisation only — the ids then still match for
-well-formed input."""
+"""Prompt -> token ids in front of the umT5 encoder: the `HuggingfaceTokenizer` the reference builds in
+T5EncoderModel (wan/modules/tokenizers.py:50-82; used at t5.py:500-513 with clean='whitespace').
+
+Same constructor and call contract (`tok(texts, return_mask=True, add_special_tokens=True)` ->
+(ids [B, seq_len], mask [B, seq_len])); the text cleaning is a small table of named pipelines.
+`ftfy` (mojibake repair) is applied when it is installed; this image does not have it, and for
+well-formed prompts NFC normalisation gives the same ids."""
 import html
 import string
 import unicodedata
 
-import regex as re
+import regex
 
 __all__ = ['HuggingfaceTokenizer']
 
 try:
-    import ftfy
-    _fix = ftfy.fix_text
-except ModuleNotFoundError:                     # not in this image; see module docstring
-    def _fix(text):
+    from ftfy import fix_text as _repair
+except ModuleNotFoundError:
+    def _repair(text):
         return unicodedata.normalize('NFC', text)
 
-
-def basic_clean(text):
-    return html.unescape(html.unescape(_fix(text))).strip()
-
-
-def whitespace_clean(text):
-    return re.sub(r'\s+', ' ', text).strip()
+_SPACES = regex.compile(r'\s+')
+_NO_PUNCT = str.maketrans('', '', string.punctuation)
 
 
-def canonicalize(text, keep_punctuation_exact_string=None):
-    text = text.replace('_', ' ')
-    table = str.maketrans('', '', string.punctuation)
-    if keep_punctuation_exact_string:
-        text = keep_punctuation_exact_string.join(p.translate(table) for p in text.split(keep_punctuation_exact_string))
-    else:
-        text = text.translate(table)
-    return re.sub(r'\s+', ' ', text.lower()).strip()
+def _unescape_twice(text):
+    return html.unescape(html.unescape(_repair(text))).strip()
+
+
+def _squeeze(text):
+    return _SPACES.sub(' ', text).strip()
+
+
+def _canonical(text):
+    return _squeeze(text.replace('_', ' ').translate(_NO_PUNCT).lower())
+
+
+# cleaning mode -> pipeline applied left to right
+_CLEANERS = {
+    None: (),
+    'whitespace': (_unescape_twice, _squeeze),
+    'lower': (_unescape_twice, _squeeze, str.lower),
+    'canonicalize': (_unescape_twice, _canonical),
+}
 
 
 class HuggingfaceTokenizer:
 
     def __init__(self, name, seq_len=None, clean=None, **kwargs):
-        assert clean in (None, 'whitespace', 'lower', 'canonicalize')
+        if clean not in _CLEANERS:
+            raise AssertionError(f'clean must be one of {sorted(k for k in _CLEANERS if k)} or None')
         from transformers import AutoTokenizer
         self.name, self.seq_len, self.clean = name, seq_len, clean
         self.tokenizer = AutoTokenizer.from_pretrained(name, **kwargs)
         self.vocab_size = self.tokenizer.vocab_size
 
-    def __call__(self, sequence, **kwargs):
-        return_mask = kwargs.pop('return_mask', False)
-        opts = {'return_tensors': 'pt'}
-        if self.seq_len is not None:
-            opts.update(padding='max_length', truncation=True, max_length=self.seq_len)
-        opts.update(**kwargs)
-        if isinstance(sequence, str):
-            sequence = [sequence]
-        if self.clean:
-            sequence = [self._clean(u) for u in sequence]
-        enc = self.tokenizer(sequence, **opts)
-        return (enc.input_ids, enc.attention_mask) if return_mask else enc.input_ids
+    def _prepare(self, text):
+        for step in _CLEANERS[self.clean]:
+            text = step(text)
+        return text
 
-    def _clean(self, text):
-        if self.clean == 'whitespace':
-            return whitespace_clean(basic_clean(text))
-        if self.clean == 'lower':
-            return whitespace_clean(basic_clean(text)).lower()
-        return canonicalize(basic_clean(text))
+    def __call__(self, sequence, **kwargs):
+        want_mask = kwargs.pop('return_mask', False)
+        texts = [sequence] if isinstance(sequence, str) else list(sequence)
+        call = dict(return_tensors='pt')
+        if self.seq_len is not None:      # fixed-length batches: pad and cut to seq_len (512 for the T2V path)
+            call.update(padding='max_length', truncation=True, max_length=self.seq_len)
+        call.update(kwargs)
+        enc = self.tokenizer([self._prepare(t) for t in texts], **call)
+        return (enc.input_ids, enc.attention_mask) if want_mask else enc.input_ids

@@ -203,3 +203,22 @@ def test_launcher_flags_and_defaults():
         g.generate(g._parse_args(['--ckpt_dir', '/x', '--dit_fsdp']))
     with pytest.raises(AssertionError, match='context parallel'):
         g.generate(g._parse_args(['--ckpt_dir', '/x', '--ulysses_size', '2']))
+
+
+def test_tokenizer_cleaning_modes():
+    """prompt cleaning of HuggingfaceTokenizer: (input, whitespace, lower, canonicalize) rows produced by the
+    reference's basic_clean / whitespace_clean / canonicalize (wan/modules/tokenizers.py:13-47, ftfy = NFC)."""
+    from wan.modules.tokenizers import HuggingfaceTokenizer
+    rows = [('  A  cat &amp;amp; dog\n walks ', 'A cat & dog walks', 'a cat & dog walks', 'a cat dog walks'),
+            ('Hello_World!!  It&#39;s  OK', "Hello_World!! It's OK", "hello_world!! it's ok", 'hello world its ok'),
+            (' MiXed   Case ', 'MiXed Case', 'mixed case', 'mixed case'),
+            ('tab\tsep  &lt;b&gt;', 'tab sep <b>', 'tab sep <b>', 'tab sep b'),
+            ('ünï_cödé!!', 'ünï_cödé!!', 'ünï_cödé!!', 'ünï cödé'),
+            ('a/b  c_d. E', 'a/b c_d. E', 'a/b c_d. e', 'ab c d e')]
+    tok = HuggingfaceTokenizer.__new__(HuggingfaceTokenizer)
+    for text, ws, lo, ca in rows:
+        for mode, want in (('whitespace', ws), ('lower', lo), ('canonicalize', ca), (None, text)):
+            tok.clean = mode
+            assert tok._prepare(text) == want, (mode, text)
+    with pytest.raises(AssertionError):
+        HuggingfaceTokenizer('x', clean='bogus')
