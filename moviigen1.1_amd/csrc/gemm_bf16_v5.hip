@@ -25,6 +25,30 @@ MG_DEV void v5_glds16(const void* g, void* l) { __builtin_amdgcn_global_load_lds
 static unsigned long long* g_gemm5_prof = nullptr;
 extern "C" void mg_gemm5_debug_profile(unsigned long long* dev_buf) { g_gemm5_prof = dev_buf; }
 
+// hand-issued fragment reads (base VGPR + immediate) with counted waits: hipcc guards a register ring of plain
+// LDS loads with `s_waitcnt lgkmcnt(0)` at every k-step boundary, i.e. it waits for the read it issued last
+template <int OFF>
+MG_DEV void v5_rd(bf16x8_t& dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
+}
+template <int N>
+MG_DEV void v5_wait() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(N) : "memory");
+}
+// fragment `slot` of a k-step in the order the MFMAs need them: fw0 fa0 fa1 fa2 fa3 fw1 fw2 fw3
+MG_DEV void v5_rd_slot(int slot, bf16x8_t (&fa)[4], bf16x8_t (&fw)[4], unsigned abase, unsigned wbase) {
+    switch (slot) {   // compile-time after unrolling
+        case 0: v5_rd<0>(fw[0], wbase); break;
+        case 1: v5_rd<0>(fa[0], abase); break;
+        case 2: v5_rd<4096>(fa[1], abase); break;
+        case 3: v5_rd<8192>(fa[2], abase); break;
+        case 4: v5_rd<12288>(fa[3], abase); break;
+        case 5: v5_rd<4096>(fw[1], wbase); break;
+        case 6: v5_rd<8192>(fw[2], wbase); break;
+        default: v5_rd<12288>(fw[3], wbase); break;
+    }
+}
+
 template <int EPI, bool PROF = false>
 __global__ __launch_bounds__(V5_THREADS, 1) void gemm_bf16_v5_kernel(
     const uint16_t* __restrict__ A, int64_t lda, const uint16_t* __restrict__ Wt, int64_t ldw,
@@ -90,6 +114,7 @@ __global__ __launch_bounds__(V5_THREADS, 1) void gemm_bf16_v5_kernel(
 
     const int sw = (l31 >> 1) & 7;
     const int t3 = g ^ sw;
+    const unsigned lds0 = (unsigned)(uintptr_t)(v5_lptr_t)smem;
     const int a_row_off = (wm * 128 + l31) * 128;
     const int w_row_off = V5_A_BYTES + (wn * 128 + l31) * 128;
 
@@ -113,32 +138,35 @@ __global__ __launch_bounds__(V5_THREADS, 1) void gemm_bf16_v5_kernel(
         char* lnext = smem + ((kt + 1) % V5_NSTAGE) * V5_STAGE;
         const int koff2 = (kt + 1 < nk ? kt + 1 : kt) * V5_BK;
         tick(1);
-        const char* ls = smem + (kt % V5_NSTAGE) * V5_STAGE;
-        // fragment reads run ONE k-step ahead of the MFMAs that consume them (register double buffer),
-        // one read behind every second MFMA
+        // fragment reads run ONE k-step ahead of the MFMAs that consume them (register double buffer), one
+        // read behind every second MFMA, in need-order, waits counted (LDS returns in order)
+        const unsigned lsb = lds0 + (kt % V5_NSTAGE) * V5_STAGE;
         bf16x8_t fa[2][4], fw[2][4];
-        {
-            const int coff = t3 << 4;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) fa[0][j] = *(const bf16x8_t*)(ls + a_row_off + j * 32 * 128 + coff);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) fw[0][i] = *(const bf16x8_t*)(ls + w_row_off + i * 32 * 128 + coff);
-        }
+        for (int slot = 0; slot < 8; ++slot) v5_rd_slot(slot, fa[0], fw[0], lsb + a_row_off + (t3 << 4), lsb + w_row_off + (t3 << 4));
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            const int coff = (t3 ^ ((kk + 1) << 1)) << 4;
+            const unsigned coff = (unsigned)((t3 ^ ((kk + 1) << 1)) << 4);
+            const unsigned abase = lsb + a_row_off + coff, wbase = lsb + w_row_off + coff;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
+                    const int slot = i * 2 + h;                 // 8 slots per k-step, one behind every second MFMA
+                    // reads still allowed in flight: the younger ones of the previous k-step + this k-step's so far
+                    const int fresh = kk < 3 ? slot : 0;
+                    if (slot == 0) v5_wait<5>();                // fw0 fa0 fa1 landed
+                    else if (slot == 1) { if (kk < 3) v5_wait<3 + 1>(); else v5_wait<3>(); }      // fa2 fa3
+                    else if (slot == 2) { if (kk < 3) v5_wait<2 + 2>(); else v5_wait<2>(); }      // fw1
+                    else if (slot == 4) { if (kk < 3) v5_wait<1 + 4>(); else v5_wait<1>(); }      // fw2
+                    else if (slot == 6) { if (kk < 3) v5_wait<0 + 6>(); else v5_wait<0>(); }      // fw3
+                    (void)fresh;
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int j = 2 * h; j < 2 * h + 2; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[kk & 1][i], fa[kk & 1][j], acc[i][j], 0, 0, 0);
-                    const int slot = i * 2 + h;                 // 8 slots per k-step, one behind every second MFMA
-                    if (kk < 3) {                               // next k-step's fragment `slot`
-                        if (slot < 4) fa[(kk + 1) & 1][slot] = *(const bf16x8_t*)(ls + a_row_off + slot * 32 * 128 + coff);
-                        else fw[(kk + 1) & 1][slot - 4] = *(const bf16x8_t*)(ls + w_row_off + (slot - 4) * 32 * 128 + coff);
-                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (kk < 3) v5_rd_slot(slot, fa[(kk + 1) & 1], fw[(kk + 1) & 1], abase, wbase);
                     if (kk < 2) {                               // 16 LDS-DMA pieces in the first half of the k-tile
                         const int q = kk * 8 + slot;
                         v5_glds16(gp[q] + koff2, lnext + piece_lds(q));
