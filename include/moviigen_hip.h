@@ -137,7 +137,7 @@ int mg_attn_fwd_bf16_generic(const uint16_t* q, int64_t ldq, const uint16_t* k, 
  * than 2^8 since the last rescale (P <= 256 in bf16); 0 = rescale every tile. */
 void mg_attn_set_lazy_rescale(int on);
 /* Kernel behind mg_attn_fwd_bf16_hd128 (same math in all):
- * 0 = auto (default): 3 when Lk >= 2048 (self-attention), else 1;
+ * 0 = auto (default): 3 when Lk >= 512 (self- and cross-attention of the DiT), else 1;
  * 1 = two-level lock-step kernel, 8 waves x 32 queries, LDS fragment reads scheduled by hipcc;
  * 2 = same kernel with a hand-issued ds_read_b128 ring (8 deep, counted lgkmcnt);
  * 3 = "w64": 4 waves x 64 queries, one wave per SIMD, software-pipelined in 32-key units

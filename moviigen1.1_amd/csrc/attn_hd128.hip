@@ -20,12 +20,12 @@
 // kernel) as B: a lane owns ONE query, softmax statistics are per-lane scalars.  K rows enter the
 // MFMA permuted (row bits 2<->3) so a lane's 8 consecutive accumulator registers are 8 consecutive
 // keys: P (bf16) is directly the B-operand of O^T = V^T.P^T, the A-operand the chunk
-// vp[kc][d] = V[8 keys][d].  Deferred rescale of O^T while no row maximum grew by 2^8.
+// vp[kc][d] = V[8 keys][d].  Maximum-free softmax against the running reference (att_softmax_fast).
 //
 // Two kernels share this ABI.  This file: "two-level lock-step", 8 waves x 32 queries, one barrier per
 // 64-key tile; the hot loop only knows the maximum-free softmax branch and leaves for an exact tile when
 // its check fails.  attn_hd128_w64.hip: 4 waves x 64 queries, one wave per SIMD, software-pipelined.
-// mg_attn_set_variant: 0 = auto (w64 for Lk >= 2048, else two-level), 1 = two-level with fragment reads
+// mg_attn_set_variant: 0 = auto (w64 for Lk >= 512, else two-level), 1 = two-level with fragment reads
 // scheduled by hipcc (4-deep ring), 2 = two-level with a hand-issued ds_read_b128 ring (8 deep,
 // counted lgkmcnt), 3 = w64.  What was measured and dropped in
 // round 1 (ping-pong role split, intra-wave pipelined softmax, accumulator rotation on/off: all
@@ -52,7 +52,7 @@ MG_DEV void att_glds16(const void* g, void* l) {
 struct AttState {
     f32x16_t ot[4];
     f32x16_t st[2];
-    bf16x8_t pf[2][2][2];   // [buffer][kb][h]; schedules 0-3 only use buffer 0
+    bf16x8_t pf[1][2][2];   // [buffer][kb][h] (one buffer: the two-level kernel is not double-buffered)
     float m_run, l_run;
 };
 
@@ -477,9 +477,9 @@ extern "C" int mg_attn_fwd_bf16_hd128_lse(const uint16_t* q, int64_t ldq, const 
     const float c_log2 = scale * 1.4426950408889634f;
     const dim3 grid((unsigned)(nqb * heads)), block(ATT_THREADS);
     hipStream_t st = (hipStream_t)stream;
-    // 0 = auto: the one-wave-per-SIMD "w64" kernel for long key sequences (self-attention), the
-    // two-level lock-step kernel for short ones (cross-attention: 8 key tiles, prologue-dominated)
-    const int variant = g_attn_variant == 0 ? (Lk >= 2048 ? 3 : 1) : g_attn_variant;
+    // 0 = auto: the one-wave-per-SIMD "w64" kernel from 8 key tiles up (self-attention, and the 512-key
+    // cross-attention: 660 vs 600 TFLOP/s), the two-level lock-step kernel for shorter key sequences
+    const int variant = g_attn_variant == 0 ? (Lk >= 512 ? 3 : 1) : g_attn_variant;
     if (variant == 3) return mg_attn_w64_launch(q, ldq, kp, vp, o, ldo, Lq, Lk, heads, c_log2, nqb, lse, st);
 #define ATT_LAUNCH(LZ, DP, PROF, ASM) \
     hipLaunchKernelGGL((attn_hd128_kernel<LZ, DP, PROF, ASM>), grid, block, 0, st, q, ldq, kp, vp, o, ldo, Lq, Lk, heads, c_log2, nqb, g_attn_prof, lse)
