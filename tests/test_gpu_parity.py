@@ -254,6 +254,27 @@ def test_dit_forward_vs_reference(dev, golden, tag, cfg):
         j += 1
 
 
+def test_dit_full_width_vs_oracle(dev):
+    """the REAL width (dim 5120, 40 heads x 128, ffn 13824, text 4096 -> 512 tokens), 2 layers, 512 video
+    tokens: w64 attention, 256x256 GEMMs and the fp32 head against the bf16-emulating oracle on the CPU."""
+    import wan
+    from oracle import dit
+    cfg = dict(model_type='t2v', patch_size=(1, 2, 2), text_len=512, in_dim=16, dim=5120, ffn_dim=13824, freq_dim=256,
+               text_dim=4096, out_dim=16, num_heads=40, num_layers=2, eps=1e-6)
+    P = W.make_dit_params(cfg, 3)
+    m = wan.modules.WanModel(**cfg)
+    m.load_state_dict(P)
+    m.to(dev)
+    lat = W.randn((16, 2, 32, 32), 21)                 # grid (2, 16, 16) = 512 tokens
+    ctx = W.randn((77, 4096), 22)
+    t = torch.tensor([417.0])
+    out = m([lat.to(dev)], t=t.to(dev), context=[ctx.to(dev)], seq_len=512)[0]
+    orc = dit.dit_forward(P, cfg, lat, t, ctx, 512, emulate_bf16=True)
+    assert rel_l2(out, orc) < 1.2e-2
+    ref32 = dit.dit_forward(P, cfg, lat, t, ctx, 512, emulate_bf16=False)
+    assert rel_l2(out, ref32) < 2e-2                   # the stated bf16 tolerance against the fp32 algorithm
+
+
 def test_dit_context_cache_and_determinism(dev):
     import wan
     cfg = W.SMALL_DIT_HD128
