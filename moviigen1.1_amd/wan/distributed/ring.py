@@ -26,6 +26,33 @@ def enable_ring_attention(model, group=None):
     model.sp_size = dist.get_world_size(group)
     model.sp_rank = dist.get_rank(group)
     model.ring = True
+    model.uly_group, model.uly_size, model.ring_group, model.ring_size = None, None, None, None
+    model._ws = {}
+    return model
+
+
+def enable_hybrid_sp(model, ulysses_size, ring_size, group=None):
+    """the reference CLI's `--ulysses_size U --ring_size R` (U * R == world size, generate.py:209-229): tokens are
+    sharded over all U*R ranks; ranks [g*U, (g+1)*U) form Ulysses group g (all-to-all: the group's tokens, heads/U),
+    ranks {u, u+U, u+2U, ...} form the ring that rotates the K/V blocks of the groups.  Needs heads % U == 0."""
+    if not dist.is_initialized():
+        raise RuntimeError('torch.distributed is not initialised (launch with torchrun, one process per GPU)')
+    P, rank = dist.get_world_size(group), dist.get_rank(group)
+    U, R = int(ulysses_size), int(ring_size)
+    if U * R != P:
+        raise ValueError('The number of ulysses_size and ring_size should be equal to the world size.')
+    if model.num_heads % U:
+        raise ValueError(f'`num_heads` {model.num_heads} cannot be divided evenly by the ulysses size {U}')
+    if R > 1 and model.dim // model.num_heads != 128:
+        raise NotImplementedError('ring attention is built on the head_dim 128 kernels')
+    glob = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
+    uly_groups = [dist.new_group([glob(g * U + u) for u in range(U)]) for g in range(R)]     # every rank creates every group
+    ring_groups = [dist.new_group([glob(u + g * U) for g in range(R)]) for u in range(U)]
+    model.sp_group = group if group is not None else dist.group.WORLD
+    model.sp_size, model.sp_rank = P, rank
+    model.uly_group, model.uly_size = uly_groups[rank // U], U
+    model.ring_group, model.ring_size, model.ring_rank = ring_groups[rank % U], R, rank // U
+    model.ring = R > 1
     model._ws = {}
     return model
 

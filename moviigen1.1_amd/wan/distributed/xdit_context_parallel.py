@@ -17,6 +17,7 @@ def enable_sequence_parallel(model, group=None):
     model.sp_group = group if group is not None else dist.group.WORLD
     model.sp_size = size
     model.sp_rank = dist.get_rank(group)
+    model.ring, model.uly_group, model.uly_size, model.ring_group, model.ring_size = False, None, None, None, None
     model._ws = {}
     return model
 

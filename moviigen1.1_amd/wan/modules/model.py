@@ -140,6 +140,9 @@ class WanModel(nn.Module):
         self.sp_size, self.sp_rank, self.sp_group = 1, 0, None
         self.sp_force = False   # run the Ulysses collectives even on a 1-rank group (RCCL smoke test)
         self.ring = False       # sequence parallelism by ring attention instead of Ulysses (wan/distributed/ring.py)
+        # hybrid layout (wan/distributed/ring.py: enable_hybrid_sp): Ulysses inside groups of `uly_size` consecutive
+        # ranks, ring attention across the `ring_size` groups; None = derive from sp_size / ring
+        self.uly_group, self.uly_size, self.ring_group, self.ring_size, self.ring_rank = None, None, None, None, 0
         self._packed = None
         self._ws = {}
         self._rope = {}
@@ -259,6 +262,12 @@ class WanModel(nn.Module):
             return lw
         return {**lw, **sh.fetch(i)}
 
+    def _sp_layout(self):
+        """(U, R): Ulysses degree inside a group, ring degree across groups; U * R == sp_size."""
+        if self.uly_size is not None:
+            return self.uly_size, self.ring_size
+        return (1, self.sp_size) if self.ring else (self.sp_size, 1)
+
     def _workspace(self, L, dev):
         key = (L, str(dev))
         ws = self._ws.get(key)
@@ -273,18 +282,19 @@ class WanModel(nn.Module):
                       hf=e(L, d, dt=f32), y=e(L, math.prod(self.patch_size) * self.out_dim, dt=f32),
                       sin=e(1, self.freq_dim, dt=f32), e1=e(d, dt=f32), e=e(d, dt=f32), e0=e(6, d, dt=f32),
                       mod=e(6 * self.num_layers, d, dt=f32), hmod=e(2, d, dt=f32))
-            if hd == 128 and not (self.ring and self.sp_size > 1):   # K / V packed into 64-key tiles (operand layout of the MFMA attention kernel)
-                n_pk = ops.packed_kv_numel(Ltot, self.num_heads // self.sp_size)
+            U, R = self._sp_layout()
+            n_loc, Lg = self.num_heads // U, L * U          # heads and tokens a rank attends after the Ulysses exchange
+            if hd == 128 and R == 1:   # K / V packed into 64-key tiles (operand layout of the MFMA attention kernel)
+                n_pk = ops.packed_kv_numel(Lg, n_loc)
                 ws['kp'], ws['vp'] = e(n_pk), e(n_pk)
-            if self.ring and self.sp_size > 1:
-                n1 = ops.packed_kv_numel(L, self.num_heads)
+            if U > 1 or self.sp_force:
+                ws['qg'], ws['kg'], ws['vg'] = e(Lg, n_loc * hd), e(Lg, n_loc * hd), e(Lg, n_loc * hd)
+                ws['ag'] = e(Lg, n_loc * hd)
+            if R > 1:                  # ring attention: two packed K/V blocks in flight, fp32 running result
+                n1 = ops.packed_kv_numel(Lg, n_loc)
                 ws['kp0'], ws['vp0'], ws['kp1'], ws['vp1'] = e(n1), e(n1), e(n1), e(n1)
-                ws['part'], ws['acc'] = e(L, d), e(L, d, dt=f32)
-                ws['lse'], ws['lse_acc'] = e(self.num_heads, L, dt=f32), e(self.num_heads, L, dt=f32)
-            elif self.sp_size > 1 or self.sp_force:
-                n_loc = self.num_heads // self.sp_size
-                ws['qg'], ws['kg'], ws['vg'] = e(Ltot, n_loc * hd), e(Ltot, n_loc * hd), e(Ltot, n_loc * hd)
-                ws['ag'] = e(Ltot, n_loc * hd)
+                ws['part'], ws['acc'] = e(Lg, n_loc * hd), e(Lg, n_loc * hd, dt=f32)
+                ws['lse'], ws['lse_acc'] = e(n_loc, Lg, dt=f32), e(n_loc, Lg, dt=f32)
             self._ws = {key: ws}  # one live shape at a time (activations are GBs at 14B/720p)
         return ws
 
@@ -357,23 +367,28 @@ class WanModel(nn.Module):
             else:
                 self._attention(ws['q'], ws['k'], qkv[:, 2 * d:], ws['a'], self._kv_valid, N)
             return
-        if self.ring:
-            from ..distributed.ring import ring_attention
-            ring_attention(ws['q'], ws['k'], qkv[:, 2 * d:], ws['a'], ws, self.sp_group, self.sp_size, self.sp_rank, N,
-                           1.0 / math.sqrt(hd))
-            return
         from ..distributed import ulysses
-        n_loc = N // self.sp_size
-        ulysses.seq_to_head(ws['q'], ws['qg'], self.sp_group, self.sp_size, N, hd)
-        ulysses.seq_to_head(ws['k'], ws['kg'], self.sp_group, self.sp_size, N, hd)
-        ulysses.seq_to_head(qkv[:, 2 * d:], ws['vg'], self.sp_group, self.sp_size, N, hd)
-        Ltot = L * self.sp_size
-        if hd == 128:
-            ops.pack_kv(ws['kg'], ws['vg'], n_loc, ws['kp'], ws['vp'])
-            self._attention(ws['qg'], ws['kp'], ws['vp'], ws['ag'], Ltot, n_loc)
+        U, R = self._sp_layout()
+        ug = self.uly_group if self.uly_group is not None else self.sp_group
+        rg = self.ring_group if self.ring_group is not None else self.sp_group
+        rr = self.ring_rank if self.uly_size is not None else self.sp_rank
+        n_loc, Lg = N // U, L * U
+        q, k, v, a = ws['q'], ws['k'], qkv[:, 2 * d:], ws['a']
+        if U > 1 or self.sp_force:          # Ulysses: tokens of the group, heads / U
+            ulysses.seq_to_head(q, ws['qg'], ug, U, N, hd)
+            ulysses.seq_to_head(k, ws['kg'], ug, U, N, hd)
+            ulysses.seq_to_head(v, ws['vg'], ug, U, N, hd)
+            q, k, v, a = ws['qg'], ws['kg'], ws['vg'], ws['ag']
+        if R > 1:                           # ring attention across the groups (hd 128 only)
+            from ..distributed.ring import ring_attention
+            ring_attention(q, k, v, a, ws, rg, R, rr, n_loc, 1.0 / math.sqrt(hd))
+        elif hd == 128:
+            ops.pack_kv(k, v, n_loc, ws['kp'], ws['vp'])
+            self._attention(q, ws['kp'], ws['vp'], a, Lg, n_loc)
         else:
-            self._attention(ws['qg'], ws['kg'], ws['vg'], ws['ag'], Ltot, n_loc)
-        ulysses.head_to_seq(ws['ag'], ws['a'], self.sp_group, self.sp_size, N, hd)
+            self._attention(q, k, v, a, Lg, n_loc)
+        if U > 1 or self.sp_force:
+            ulysses.head_to_seq(ws['ag'], ws['a'], ug, U, N, hd)
 
     @torch.no_grad()
     def _forward_one(self, lat, t, ctx, seq_len):
@@ -390,7 +405,7 @@ class WanModel(nn.Module):
         if P > 1:
             # reference SP path does not mask padded keys (xdit_context_parallel.py:178-193): it is
             # only correct without padding, which is what every supported size gives
-            assert seq_len == Lfull and Lfull % P == 0 and (self.ring or self.num_heads % P == 0), \
+            assert seq_len == Lfull and Lfull % P == 0 and self.num_heads % self._sp_layout()[0] == 0, \
                 'sequence parallel needs L % sp == 0, heads % sp == 0 and no padding'
         L = Lfull // P
         pos0 = self.sp_rank * L

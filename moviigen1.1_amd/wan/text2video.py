@@ -30,7 +30,7 @@ from .utils.fm_solvers_unipc import FlowUniPCMultistepScheduler
 class WanT2V:
 
     def __init__(self, config, checkpoint_dir, device_id=0, rank=0, t5_fsdp=False, dit_fsdp=False, use_usp=False,
-                 t5_cpu=False, text_encoder=None, model=None, vae=None, cfg_parallel=False, vae_parallel=False, use_ring=False):
+                 t5_cpu=False, text_encoder=None, model=None, vae=None, cfg_parallel=False, vae_parallel=False, use_ring=False, sp_degrees=None):
         self.device = torch.device(f'cuda:{device_id}')
         self.config = config
         self.rank = rank
@@ -64,11 +64,17 @@ class WanT2V:
             # cond / uncond halves, Ulysses inside each half (wan/distributed/cfg_parallel.py)
             from .distributed.cfg_parallel import enable_cfg_parallel
             self.cfgp = enable_cfg_parallel(self.model)
-        if use_usp and use_ring:
+        if use_usp and (use_ring or sp_degrees):
             if cfg_parallel:
-                raise NotImplementedError('cfg_parallel is built on Ulysses groups; ring attention runs over all ranks')
-            from .distributed.ring import enable_ring_attention
-            enable_ring_attention(self.model)
+                raise NotImplementedError('cfg_parallel is built on plain Ulysses groups')
+            from .distributed.ring import enable_hybrid_sp, enable_ring_attention
+            if sp_degrees and sp_degrees[0] > 1 and sp_degrees[1] > 1:      # (ulysses_size, ring_size)
+                enable_hybrid_sp(self.model, *sp_degrees)
+            elif use_ring or (sp_degrees and sp_degrees[1] > 1):
+                enable_ring_attention(self.model)
+            else:
+                from .distributed.xdit_context_parallel import enable_sequence_parallel
+                enable_sequence_parallel(self.model)
         elif use_usp and self.cfgp is None:
             from .distributed.xdit_context_parallel import enable_sequence_parallel
             enable_sequence_parallel(self.model)

@@ -7,9 +7,8 @@ file naming (generate.py:300-306), on the MI355X engine.
     torchrun --nproc_per_node 8 --master-addr 127.0.0.1 scripts/inference/generate.py ... \\
         --dit_fsdp --t5_fsdp --ulysses_size 8          (the reference's inference.sh line)
 
-Differences: no xfuser (sequence parallelism is built in; `--ulysses_size N` or `--ring_size N`
-must equal the world size as in the reference; the hybrid of both is not built), `--use_prompt_extend`
-is not built and says so,
+Differences: no xfuser (sequence parallelism is built in; `--ulysses_size U` x `--ring_size R`
+must equal the world size as in the reference), `--use_prompt_extend` is not built and says so,
 `--t5_fsdp` / `--t5_cpu` are accepted (the 9.4 GB encoder is simply replicated on the GPU).  Extra:
 `--cfg_parallel`, `--vae_parallel` (this engine's multi-GPU layouts) and
 `--prompt_embeds FILE` (a torch file {'prompt': [len,4096], 'negative': [len,4096]} instead of running
@@ -131,8 +130,6 @@ def generate(args):
     if args.ulysses_size > 1 or args.ring_size > 1:
         assert args.ulysses_size * args.ring_size == world, \
             'The number of ulysses_size and ring_size should be equal to the world size.'
-    if args.ulysses_size > 1 and args.ring_size > 1:
-        raise NotImplementedError('hybrid Ulysses x ring layouts are not built: use --ulysses_size N or --ring_size N')
     if args.use_prompt_extend:
         raise NotImplementedError('prompt extension (a 7B LLM rewriter) is outside this engine: pass the rewritten prompt')
     cfg = WAN_CONFIGS[args.task]
@@ -152,7 +149,8 @@ def generate(args):
     logging.info('Creating WanT2V pipeline.')
     pipe = wan.WanT2V(config=cfg, checkpoint_dir=args.ckpt_dir, device_id=local, rank=rank, t5_fsdp=args.t5_fsdp,
                       dit_fsdp=args.dit_fsdp, use_usp=(args.ulysses_size > 1 or args.ring_size > 1), t5_cpu=args.t5_cpu,
-                      cfg_parallel=args.cfg_parallel, vae_parallel=args.vae_parallel, use_ring=args.ring_size > 1)
+                      cfg_parallel=args.cfg_parallel, vae_parallel=args.vae_parallel,
+                      sp_degrees=(args.ulysses_size, args.ring_size) if args.ring_size > 1 else None)
     prompt, n_prompt = args.prompt, ''
     if args.prompt_embeds:
         emb = torch.load(args.prompt_embeds, map_location='cpu', weights_only=True)

@@ -61,5 +61,15 @@ got = m([lat], t=t, context=[ctx], seq_len=Lm)[0]
 rel = ((got - single).norm() / single.norm()).item()
 assert rel < 5e-3, rel
 print(f'RING_MODEL_OK rank{rank}/{P} rel {rel:.2e}', flush=True)
+
+# ---- hybrid: Ulysses 2 x ring P/2 (the reference CLI's --ulysses_size 2 --ring_size P/2) ---------------------
+if P % 2 == 0 and P >= 4:
+    from wan.distributed.ring import enable_hybrid_sp
+    enable_hybrid_sp(m, 2, P // 2)
+    assert m._sp_layout() == (2, P // 2) and m.sp_size == P
+    got = m([lat], t=t, context=[ctx], seq_len=Lm)[0]
+    rel = ((got - single).norm() / single.norm()).item()
+    assert rel < 5e-3, rel
+    print(f'HYBRID_OK rank{rank}/{P} rel {rel:.2e}', flush=True)
 dist.barrier()
 dist.destroy_process_group()

@@ -565,7 +565,7 @@ def test_vae_pipelined_one_gpu(world):
         assert f'VAEPIPE_OK rank{k}/{world}' in r.stdout
 
 
-@pytest.mark.parametrize('world', [2, 3])
+@pytest.mark.parametrize('world', [2, 3, 4])
 def test_ring_attention_one_gpu(world):
     """ring attention (operator and whole forward) vs one long softmax, head counts not divisible by the ring size."""
     import os
@@ -578,6 +578,7 @@ def test_ring_attention_one_gpu(world):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     for k in range(world):
         assert f'RING_OP_OK rank{k}/{world}' in r.stdout and f'RING_MODEL_OK rank{k}/{world}' in r.stdout
+        assert world != 4 or f'HYBRID_OK rank{k}/{world}' in r.stdout
 
 
 def test_attention_lse_and_merge(dev):
