@@ -1,17 +1,23 @@
 """bench.py — denoise-steps/sec of the MoviiGen1.1 14B T2V hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 720p|1080p|1056p|tiny]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 1080p|720p|1056p|tiny]
 
 One "step" = what one iteration of the reference loop does (wan/text2video.py:233-254):
 two WanModel forwards (cond / uncond), the CFG combine and one UniPC scheduler step, on
-synthetic data of BASELINE.json configs[1] (N=1: 14B, 1280x720x81f, L = 75 600 tokens).
+synthetic data of the configuration BASELINE.json's `metric` is quoted on: 14B T2V,
+1920x832x81f (latent [16,21,104,240], L = 131 040 tokens) — it fits one MI355X, so N=1 runs
+it unsharded (`--workload 720p` = BASELINE configs[1], 1280x720x81f, L = 75 600).
 N>1 (launched by torch.distributed.run, one rank per GPU): the SAME video with Ulysses
 sequence parallelism over RCCL -> strong scaling.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (self-attention, 72 % of
-the FLOPs): algorithmic FLOPs per launch / mean launch duration, measured live with events on the
-launch stream during the timed region.  `cpu_baseline` times the ORACLE (oracle/dit.py, the CPU
-restatement) on a bounded slice on this box's host cores and extrapolates by the FLOP formula.
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (self-attention, 82 % of
+the FLOPs at this size): algorithmic FLOPs per launch / mean launch duration, measured live with
+events on the launch stream during the timed region.  After the timed region the same process
+measures what is left of `sec/video` (reference wan/text2video.py:228-261): the WanVAE decode of a
+latent of the workload's size and (reported separately, as SURVEY.md §8(d) prescribes) the two
+umT5-XXL prompt encodes; `sec_per_video` = 50 x the measured step + the measured decode.
+`cpu_baseline` times the ORACLE (oracle/dit.py, oracle/vae.py: the CPU restatements) on bounded
+slices on this box's host cores and extrapolates by the FLOP formulas (rule stated in the line).
 """
 import argparse
 import json
@@ -29,11 +35,12 @@ import torch.distributed as dist  # noqa: E402
 
 WORKLOADS = {  # name -> (W, H, frames, description)
     '720p': (1280, 720, 81, '14B T2V 1280x720x81f bf16 (BASELINE configs[1])'),
-    '1080p': (1920, 832, 81, '14B T2V 1920x832x81f bf16 (BASELINE configs[2] shape)'),
+    '1080p': (1920, 832, 81, "14B T2V 1920x832x81f bf16 (the metric's configuration; BASELINE configs[2] shape)"),
     '1056p': (1920, 1056, 81, '14B T2V 1920x1056x81f bf16 (BASELINE configs[3] shape)'),
     'tiny': (128, 96, 9, 'plumbing check: 14B width, 2 layers, 128x96x9f'),
 }
 PEAK_BF16 = 2.5e15   # dense MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_F32_MFMA = 157.3e12   # exact-f32 MFMA peak (same table)
 MODEL_14B = dict(dim=5120, ffn_dim=13824, freq_dim=256, num_heads=40, num_layers=40, text_len=512, text_dim=4096,
                  in_dim=16, out_dim=16, eps=1e-6)
 
@@ -58,36 +65,86 @@ def _usable_cores():
     return max(1, min(n, 64))
 
 
-def cpu_baseline(budget_s=12.0):
-    """oracle (CPU restatement, fp32) on a bounded slice: ONE 14B-width block at L=512
-    (grid 2x16x16), all host cores; extrapolated to steps/s of the 720p workload by FLOPs."""
+def vae_decode_flops(T, h, w):
+    """(total, attention) FLOPs of WanVAE.decode for a latent [16,T,h,w] (reference vae.py:367-472 layout,
+    SURVEY.md Appendix A): 1116.5 TF at (21,104,240), 639.2 TF at (21,90,160) — SURVEY §8(d)."""
+    px, F0, F1, F2 = h * w, T, 1 + 2 * (T - 1), 1 + 4 * (T - 1)
+    res = lambda cin, cout: 27 * cin * cout + 27 * cout * cout + (cin * cout if cin != cout else 0)  # noqa: E731
+    attn = 2 * px * px * 384 * F0
+    mac = (16 * 16 + 27 * 16 * 384 + 2 * res(384, 384) + 384 * 1152 + 384 * 384 + 3 * res(384, 384)) * px * F0 + attn
+    mac += 3 * 384 * 768 * px * (F0 - 1) + (9 * 384 * 192 + res(192, 384) + 2 * res(384, 384)) * 4 * px * F1
+    mac += 3 * 384 * 768 * 4 * px * (F1 - 1) + (9 * 384 * 192 + 3 * res(192, 192)) * 16 * px * F2
+    mac += (9 * 192 * 96 + 3 * res(96, 96) + 27 * 96 * 3) * 64 * px * F2
+    return 2 * mac, 2 * attn
+
+
+def cpu_baseline(L_step, lat_shape):
+    """The oracle (CPU restatement, fp32, all usable host cores) on the bounded slices SURVEY.md §8(d) names:
+      * ONE 14B-width WanAttentionBlock (d=5120, 40 heads, ffn 13824, 512 text keys) at L = 4 096 (grid 4x32x32),
+        and its self-attention alone on the same shapes, so the step is extrapolated in two parts:
+        t_step = F_linear(step) / r_linear + F_attention(step) / r_attention  (FLOP formula of SURVEY §8(d));
+      * BASELINE configs[0] in full (2-layer dim-128 DiT, latent [16,1,8,8], 2 UniPC steps with CFG);
+      * the VAE decode of z[16,5,32,32] -> [3,17,256,256], extrapolated to the workload's latent by FLOPs."""
     import weights as W
-    from oracle import dit
+    from oracle import dit, schedulers as osch, vae as ovae
     torch.set_num_threads(_usable_cores())
-    cfg = dict(W.TINY_DIT, dim=5120, ffn_dim=13824, num_heads=40, num_layers=1, text_len=512)
+    d, f, N = 5120, 13824, 40
+    cfg = dict(W.TINY_DIT, dim=d, ffn_dim=f, num_heads=N, num_layers=1, text_len=512)
     g = torch.Generator().manual_seed(0)
     shapes = {k: v for k, v in W.dit_param_shapes(cfg).items() if k.startswith('blocks.0.')}
     P = {k: (torch.randn(s, generator=g) * 0.02) for k, s in shapes.items()}
-    L = 512
-    x = torch.randn(L, 5120, generator=g)
-    e0 = torch.randn(6, 5120, generator=g) * 0.1
-    ctx = torch.randn(512, 5120, generator=g)
+    L, grid = 4096, (4, 32, 32)
+    x = torch.randn(L, d, generator=g)
+    e0 = torch.randn(6, d, generator=g) * 0.1
+    ctx = torch.randn(512, d, generator=g)
     tabs = dit.rope_table(128)
-    run = lambda: dit.block(P, 'blocks.0.', x, e0, L, (2, 16, 16), tabs, ctx, 40, 1e-6, False, False)  # noqa: E731
-    run()
-    t0, n = time.time(), 0
-    while n < 1 or (time.time() - t0 < budget_s and n < 20):
-        run()
-        n += 1
-    dt = (time.time() - t0) / n
-    d, f = 5120, 13824
-    blk = 12 * L * d * d + 4 * 512 * d * d + 4 * L * d * f + 4 * L * L * d + 4 * L * 512 * d
-    gflops = blk / dt / 1e9
-    step_flops = 2 * flops_per_forward(75600, MODEL_14B)
-    return {'value': gflops * 1e9 / step_flops, 'unit': 'steps/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'gflops': round(gflops, 1),
-            'sample': f'oracle/dit.py block (d=5120, 40 heads, ffn=13824) at L=512, {n} runs of {dt:.2f}s, '
-                      f'extrapolated to the 720p step (13.05 PFLOP) by the FLOP formula'}
+
+    def timed(fn, reps):
+        fn()
+        t0 = time.time()
+        for _ in range(reps):
+            fn()
+        return (time.time() - t0) / reps
+    t_blk = timed(lambda: dit.block(P, 'blocks.0.', x, e0, L, grid, tabs, ctx, N, 1e-6, False, False), 1)
+    q = torch.randn(L, N, 128, generator=g)
+    t_att = timed(lambda: dit.attention(q, q, q, L, False), 2)
+    F_att = 4 * L * L * d
+    F_lin = 12 * L * d * d + 4 * 512 * d * d + 4 * L * d * f + 4 * L * 512 * d
+    r_att, r_lin = F_att / t_att, F_lin / max(t_blk - t_att, 1e-9)
+    fl_fwd = flops_per_forward(L_step, MODEL_14B)
+    F_att_step = 2 * MODEL_14B['num_layers'] * 4 * L_step * L_step * d
+    F_lin_step = 2 * fl_fwd - F_att_step
+    t_step = F_lin_step / r_lin + F_att_step / r_att
+
+    # BASELINE configs[0], in full
+    c0 = W.TINY_DIT
+    P0 = W.make_dit_params(c0, 0)
+    lat0, ctx0, ctxn0 = W.randn((16, 1, 8, 8), 1), W.randn((11, c0['text_dim']), 2), W.randn((5, c0['text_dim']), 3)
+    t0 = time.time()
+    osch.sample_loop(lambda lat, t, c: dit.dit_forward(P0, c0, lat, t, c, 16), lat0, ctx0, ctxn0, 2, 5.0, 5.0, 'unipc')
+    t_cfg0 = time.time() - t0
+
+    # VAE slice
+    Pv = W.make_vae_params(96, 1)
+    z = torch.randn(16, 5, 32, 32, generator=g)
+    t0 = time.time()
+    ovae.vae_decode(Pv, z)
+    t_vae = time.time() - t0
+    fv_slice = vae_decode_flops(5, 32, 32)[0]
+    fv_full = vae_decode_flops(*lat_shape[1:])[0]
+    return {'value': 1.0 / t_step, 'unit': 'steps/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'block_L4096_s': round(t_blk, 3), 'attention_L4096_s': round(t_att, 3),
+            'gflops_linear': round(r_lin / 1e9, 1), 'gflops_attention': round(r_att / 1e9, 1),
+            'sec_per_step_extrapolated': round(t_step, 1),
+            'config0_2steps_s': round(t_cfg0, 3),
+            'vae': {'slice_s': round(t_vae, 2), 'gflops': round(fv_slice / t_vae / 1e9, 1),
+                    'decode_s_extrapolated': round(fv_full / (fv_slice / t_vae), 1),
+                    'sample': 'oracle/vae.py vae_decode of z[16,5,32,32] -> [3,17,256,256] (dim-96 decoder), 1 run, '
+                              'extrapolated to the workload latent by the decoder FLOP count'},
+            'sample': f'oracle/dit.py block (d=5120, 40 heads, ffn=13824, 512 text keys) at L=4096: {t_blk:.2f}s per run, '
+                      f'its self-attention alone {t_att:.2f}s; rule: t_step = F_linear/r_linear + F_attention/r_attention '
+                      f'with the step FLOPs of SURVEY 8(d) ({2 * fl_fwd / 1e15:.2f} PFLOP at L={L_step}); '
+                      f'configs[0] (2-layer dim-128 DiT, 2 UniPC steps, CFG) in full: {t_cfg0:.2f}s'}
 
 
 def main():
@@ -95,8 +152,10 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=1)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--workload', default='720p', choices=sorted(WORKLOADS))
+    ap.add_argument('--workload', default='1080p', choices=sorted(WORKLOADS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-video-tail', action='store_true',
+                    help='skip the VAE decode / T5 legs measured after the timed region (profiling passes)')
     ap.add_argument('--no-cfg-parallel', action='store_true',
                     help='N > 1: Ulysses over all N ranks (the reference layout) instead of cond/uncond halves x Ulysses N/2')
     ap.add_argument('--layers', type=int, default=None, help='debug only: fewer layers (marks the line invalid)')
@@ -206,6 +265,52 @@ def main():
         elapsed = tt.item()
     assert torch.isfinite(latent).all().item(), 'non-finite latent'
 
+    # ---- the rest of sec/video (reference wan/text2video.py:228-261), measured in this same process after the timed
+    # region: WanVAE.decode of a latent of this size on rank 0 (the reference decodes on rank 0 only) and, reported
+    # separately, the two umT5-XXL prompt encodes.  Random-init weights of the shipped architectures.
+    vae_s = t5_s = None
+    if rank == 0 and not args.no_video_tail:
+        import weights as Wt
+        z = latent.clone()
+        model._ws = {}                       # the DiT activations are not needed any more
+        torch.cuda.empty_cache()
+        vae = wan.modules.WanVAE(state_dict=Wt.make_vae_params(96, 1), device=dev)
+        vae.decode([z[:, :2, :16, :16].contiguous()])        # warm-up launch of every kernel (tiny latent)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        video = vae.decode([z])[0]
+        torch.cuda.synchronize()
+        vae_s = time.perf_counter() - t1
+        assert video.shape == (3, frames, Hd, Wd) and torch.isfinite(video).all().item()
+        del video, vae
+        torch.cuda.empty_cache()
+        if not args.layers and args.workload != 'tiny':
+            from wan.modules.t5 import umt5_xxl
+            enc = umt5_xxl(device=dev)
+            gt = torch.Generator(device=dev).manual_seed(0)
+            for name, p in enc.named_parameters():
+                if 'norm' in name:
+                    p.data.fill_(1.0)
+                else:
+                    p.data.copy_(torch.randn(p.shape, generator=gt, device=dev, dtype=torch.float32)
+                                 .mul_(p.shape[-1] ** -0.5 * 0.5))
+            ids = torch.randint(1, 256384, (1, 512), generator=torch.Generator().manual_seed(1)).to(dev)
+            masks = []
+            for n in (512, 130):                             # prompt and negative prompt (SURVEY 8(d) lengths)
+                mk = torch.zeros(1, 512, dtype=torch.long, device=dev)
+                mk[:, :n] = 1
+                masks.append(mk)
+            for mk in masks:
+                enc(ids, mk)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for mk in masks:
+                enc(ids, mk)
+            torch.cuda.synchronize()
+            t5_s = time.perf_counter() - t1
+            del enc
+            torch.cuda.empty_cache()
+
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
         fl_fwd = flops_per_forward(L, cfg)
@@ -213,6 +318,10 @@ def main():
         heads_loc = cfg['num_heads'] // sp
         attn_flops = 4.0 * L * L * 128 * heads_loc
         ach = attn_flops / (attn_ms * 1e-3) / 1e12 if attn_events else None
+        # the cross-attention K/V projections and the text embedding are per-prompt work cached outside the timed
+        # region (WanModel._context): they are NOT counted in the executed-FLOP rate
+        fl_cached = cfg['num_layers'] * 4 * 512 * cfg['dim'] ** 2 + 2 * 512 * (4096 * cfg['dim'] + cfg['dim'] ** 2)
+        fl_step = 2 * (fl_fwd - fl_cached)
         line = {
             'metric': 'denoise-steps/sec', 'value': args.steps / elapsed, 'unit': 'steps/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_step, 'higher_is_better': True,
@@ -220,20 +329,31 @@ def main():
             'config': {'workload': desc, 'latent': list(lat_shape), 'tokens': L, 'layers': cfg['num_layers'],
                        'parallelism': ('single' if world == 1 else f'cfg2 x ulysses_sp{sp}' if cfgp is not None else f'ulysses_sp{sp}'), 'solver': 'unipc',
                        'guide_scale': 5.0, 'weights': 'random N(0,0.02) bf16, seed 0'},
-            'sec_per_video_50steps_dit_only': ms_step * 50 / 1e3,
-            'model_tflops_per_gpu': 2 * fl_fwd / (elapsed / args.steps) / world / 1e12,
-            'mfma_frac_whole_step': 2 * fl_fwd / (elapsed / args.steps) / world / PEAK_BF16,
+            'sec_per_video': (ms_step * 50 / 1e3 + vae_s) if vae_s is not None else None,
+            'sec_per_video_parts': {'denoise_50_steps_s': ms_step * 50 / 1e3, 'vae_decode_s': vae_s,
+                                    't5_encode_2_prompts_s_not_included': t5_s,
+                                    'note': '50 x the measured step + the measured WanVAE.decode of this latent size, same '
+                                            'process; T5 reported separately (SURVEY 8(d))'},
+            'model_tflops_per_gpu': fl_step / (elapsed / args.steps) / world / 1e12,
+            'mfma_frac_whole_step': fl_step / (elapsed / args.steps) / world / PEAK_BF16,
             'roofline': {'kernel': 'attn_hd128_w64_kernel (self-attention, mg_attn_fwd_bf16_hd128)', 'bound': 'mfma',
                          'achieved': ach, 'peak': PEAK_BF16 / 1e12, 'unit': 'TFLOP/s',
                          'frac': (ach * 1e12 / PEAK_BF16) if ach else None, 'traffic': None,
                          'launches_timed': len(attn_events), 'ms_per_launch': attn_ms,
                          'algorithmic_flops_per_launch': attn_flops},
         }
+        if vae_s is not None:
+            fv = vae_decode_flops(*lat_shape[1:])[0]
+            line['vae_decode'] = {'seconds': vae_s, 'latent': list(lat_shape), 'tflops_fp32': fv / vae_s / 1e12,
+                                  'fp32_mfma_peak_tflops': PEAK_F32_MFMA / 1e12, 'frac': fv / vae_s / PEAK_F32_MFMA,
+                                  'algorithmic_tflop': fv / 1e12}
         # HBM-side traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this same
-        # command (tools/round_end_gpu.sh); the newest committed summary is reported, never a guess
-        if args.workload == '720p' and world == 1 and not args.layers:
+        # command (tools/round_end_gpu.sh); the newest committed summary FOR THIS WORKLOAD is reported, never a guess
+        if world == 1 and not args.layers:
             import glob
-            found = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*pmc_traffic.json')))
+            found = sorted(glob.glob(os.path.join(ROOT, 'profiles', f'*pmc_traffic_{args.workload}.json')))
+            if not found and args.workload == '720p':
+                found = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*pmc_traffic.json')))
             if found:
                 with open(found[-1]) as f:
                     pmc = json.load(f)
@@ -244,7 +364,7 @@ def main():
         if args.layers or args.workload == 'tiny':
             line['invalid'] = 'debug configuration (not the BASELINE model)'
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline()
+            line['cpu_baseline'] = cpu_baseline(L, lat_shape)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

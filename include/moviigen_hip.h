@@ -250,6 +250,11 @@ int mg_vae_video_out_f32(const float* x, int C, int T, int H, int W, float* out,
 int mg_video_to_u8(const float* video, int T, int H, int W, float lo, float hi, uint8_t* frames,
                    void* stream);
 
+/* One decoded frame [3][H][W] fp32 -> uint8 pixels [H][W][3] as the reference's cache_image writes a t2i result
+ * (wan/utils/utils.py:64-91 -> torchvision save_image): clamp(lo,hi), (x-lo)/max(hi-lo,1e-5), *255, +0.5,
+ * clamp(0,255), truncating cast. */
+int mg_image_to_u8(const float* image, int H, int W, float lo, float hi, uint8_t* pixels, void* stream);
+
 /* time_conv channel halves -> interleaved frames (vae.py:133-137):
  * x [T][H][W][2C] -> out [2T][H][W][C], frame 2t from channels [0,C), 2t+1 from [C,2C). */
 int mg_vae_time_interleave_f32(const float* x, int T, int64_t HW, int C, float* out, void* stream);

@@ -375,6 +375,7 @@ extern "C" int mg_vae_video_out_f32(const float* x, int C, int T, int H, int W, 
 // decoded video [3][T][H][W] fp32 -> uint8 frames [T][H][W][3], the arithmetic of the reference's
 // cache_video for one video (wan/utils/utils.py:39-47: clamp to the value range, torchvision
 // make_grid normalisation (x - lo) / max(hi - lo, 1e-5), * 255, truncating cast)
+template <bool ROUND>
 __global__ void video_to_u8_kernel(const float* __restrict__ v, int T, int64_t hw, float lo, float hi,
                                    uint8_t* __restrict__ out) {
     const int64_t total = (int64_t)T * hw;
@@ -384,7 +385,9 @@ __global__ void video_to_u8_kernel(const float* __restrict__ v, int T, int64_t h
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float x = fminf(hi, fmaxf(lo, v[(int64_t)c * total + i]));
-            px[c] = (uint8_t)(int)(((x - lo) / span) * 255.f);
+            const float y = ((x - lo) / span) * 255.f;
+            // ROUND: torchvision save_image (mul 255, add 0.5, clamp 0..255, truncate) — the reference's cache_image
+            px[c] = (uint8_t)(int)(ROUND ? fminf(255.f, fmaxf(0.f, y + 0.5f)) : y);
         }
         out[i * 3 + 0] = px[0];
         out[i * 3 + 1] = px[1];
@@ -398,7 +401,17 @@ extern "C" int mg_video_to_u8(const float* video, int T, int H, int W, float lo,
     const int64_t hw = (int64_t)H * W;
     int64_t g = ((int64_t)T * hw + 255) / 256;
     if (g > 16384) g = 16384;
-    hipLaunchKernelGGL(video_to_u8_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, video, T, hw, lo, hi, frames);
+    hipLaunchKernelGGL(video_to_u8_kernel<false>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, video, T, hw, lo, hi, frames);
+    return mg_check_launch();
+}
+
+extern "C" int mg_image_to_u8(const float* image, int H, int W, float lo, float hi, uint8_t* pixels, void* stream) {
+    if (!image || !pixels) return MG_ERR_ARG;
+    if (H <= 0 || W <= 0 || !(hi >= lo)) return MG_ERR_SHAPE;
+    const int64_t hw = (int64_t)H * W;
+    int64_t g = (hw + 255) / 256;
+    if (g > 16384) g = 16384;
+    hipLaunchKernelGGL(video_to_u8_kernel<true>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, image, 1, hw, lo, hi, pixels);
     return mg_check_launch();
 }
 

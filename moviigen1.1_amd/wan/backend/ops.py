@@ -239,6 +239,17 @@ def video_to_u8(video, lo=-1.0, hi=1.0):
     return out
 
 
+def image_to_u8(image, lo=-1.0, hi=1.0):
+    """[3,H,W] fp32 -> uint8 pixels [H,W,3] (reference cache_image / torchvision save_image arithmetic: rounds)."""
+    _chk(image, torch.float32, 'image')
+    if image.dim() != 3 or image.shape[0] != 3 or not image.is_contiguous():
+        raise lib.MoviigenHipError('image must be a contiguous [3, H, W] tensor')
+    _, H, W = image.shape
+    out = torch.empty(H, W, 3, dtype=torch.uint8, device=image.device)
+    lib.call('mg_image_to_u8', _p(image), H, W, float(lo), float(hi), _p(out), _st())
+    return out
+
+
 def attention_hd128_lse(q, kp, vp, out, lse, lk, heads, scale):
     """attention_hd128 that also writes lse [heads, Lq] fp32 (log-sum-exp of the scaled scores)."""
     _chk(q, torch.bfloat16, 'q'); _chk(kp, torch.bfloat16, 'kp'); _chk(vp, torch.bfloat16, 'vp')

@@ -362,8 +362,9 @@ class WanModel(nn.Module):
         ops.rmsnorm_rope(qkv[:, d:2 * d], sa.norm_k.weight, self.eps, hd, ws['k'], rope, grid, pos0)
         if self.sp_size == 1 and not self.sp_force:
             if hd == 128:
-                ops.pack_kv(ws['k'], qkv[:, 2 * d:], N, ws['kp'], ws['vp'])
-                self._attention(ws['q'], ws['kp'], ws['vp'], ws['a'], self._kv_valid, N)
+                kv = self._kv_valid        # rows past the video's tokens are padding: never packed, never attended
+                ops.pack_kv(ws['k'][:kv], qkv[:kv, 2 * d:], N, ws['kp'], ws['vp'])
+                self._attention(ws['q'], ws['kp'], ws['vp'], ws['a'], kv, N)
             else:
                 self._attention(ws['q'], ws['k'], qkv[:, 2 * d:], ws['a'], self._kv_valid, N)
             return

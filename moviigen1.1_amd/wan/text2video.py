@@ -60,25 +60,32 @@ class WanT2V:
         self.model.to(self.device)
         self.cfgp = None
         self.vae_parallel = bool(vae_parallel) and dist.is_initialized() and dist.get_world_size() > 1
-        if use_usp and cfg_parallel:
-            # cond / uncond halves, Ulysses inside each half (wan/distributed/cfg_parallel.py)
+        # flag combinations are validated BEFORE any process group is created
+        want_ring = bool(use_ring or (sp_degrees and sp_degrees[1] > 1))
+        if cfg_parallel and want_ring:
+            raise NotImplementedError('cfg_parallel is built on plain Ulysses groups (no ring / hybrid layout)')
+        if cfg_parallel and not (dist.is_initialized() and dist.get_world_size() % 2 == 0):
+            logging.warning('cfg_parallel needs an even number of ranks under torch.distributed: ignored, both CFG '
+                            'forwards run on every rank')
+            cfg_parallel = False
+        if cfg_parallel:
+            # cond / uncond halves of the ranks, Ulysses inside each half when it has more than one rank
+            # (wan/distributed/cfg_parallel.py) — independent of use_usp: 2 ranks need no sequence parallelism at all
             from .distributed.cfg_parallel import enable_cfg_parallel
             self.cfgp = enable_cfg_parallel(self.model)
-        if use_usp and (use_ring or sp_degrees):
-            if cfg_parallel:
-                raise NotImplementedError('cfg_parallel is built on plain Ulysses groups')
+        elif use_usp and (use_ring or sp_degrees):
             from .distributed.ring import enable_hybrid_sp, enable_ring_attention
             if sp_degrees and sp_degrees[0] > 1 and sp_degrees[1] > 1:      # (ulysses_size, ring_size)
                 enable_hybrid_sp(self.model, *sp_degrees)
-            elif use_ring or (sp_degrees and sp_degrees[1] > 1):
+            elif want_ring:
                 enable_ring_attention(self.model)
             else:
                 from .distributed.xdit_context_parallel import enable_sequence_parallel
                 enable_sequence_parallel(self.model)
-        elif use_usp and self.cfgp is None:
+        elif use_usp:
             from .distributed.xdit_context_parallel import enable_sequence_parallel
             enable_sequence_parallel(self.model)
-        self.sp_size = self.model.sp_size if use_usp else 1
+        self.sp_size = self.model.sp_size
         if dit_fsdp:
             from .distributed.fsdp import shard_model
             self.model = shard_model(self.model, device_id=device_id)

@@ -7,6 +7,7 @@ encode is host-side as in the reference: `imageio` (libx264) when it is installe
 neither imageio nor an encoder, so the frames are then written as a raw `.npy` next to the requested
 name instead of being dropped."""
 import binascii
+import logging
 import os
 import os.path as osp
 
@@ -15,7 +16,7 @@ import torch
 
 from ..backend import ops
 
-__all__ = ['cache_video', 'video_frames_uint8', 'str2bool']
+__all__ = ['cache_video', 'cache_image', 'video_frames_uint8', 'str2bool']
 
 
 def rand_name(length=8, suffix=''):
@@ -44,7 +45,8 @@ def cache_video(tensor, save_file=None, fps=30, suffix='.mp4', nrow=8, normalize
     except ModuleNotFoundError:
         path = osp.splitext(cache_file)[0] + '.npy'
         np.save(path, frames)
-        print(f'cache_video: imageio is not installed, wrote the uint8 frames {frames.shape} to {path}', flush=True)
+        logging.info(f'cache_video: imageio is not installed, wrote the uint8 frames {frames.shape} to {path} '
+                     '(the mp4 container encode is host-side and outside this engine)')
         return path
     error = None
     for _ in range(retry):
@@ -56,7 +58,32 @@ def cache_video(tensor, save_file=None, fps=30, suffix='.mp4', nrow=8, normalize
             return cache_file
         except Exception as e:  # noqa: BLE001  (the reference retries on any writer error)
             error = e
-    print(f'cache_video failed, error: {error}', flush=True)
+    logging.error(f'cache_video failed, error: {error}')
+    return None
+
+
+def cache_image(tensor, save_file, nrow=8, normalize=True, value_range=(-1, 1), retry=5):
+    """reference wan/utils/utils.py:64-91, called for the t2i task (generate.py:308-315) with
+    `video.squeeze(1)[None]`: ONE image [1,3,H,W] -> PNG (or the suffix given).  torchvision's make_grid returns a
+    single image unpadded, so the pixels are clamp, (x-lo)/max(hi-lo,1e-5), *255, +0.5, clamp, uint8 (mg_image_to_u8)."""
+    if not normalize:
+        raise NotImplementedError('the reference always calls cache_image with normalize=True')
+    if tensor.dim() == 4:
+        if tensor.shape[0] != 1:
+            raise NotImplementedError('make_grid of several images (nrow tiling) is not on the T2V path: one image per call')
+        tensor = tensor[0]
+    if osp.splitext(save_file)[1].lower() not in ('.jpg', '.jpeg', '.png', '.tiff', '.gif', '.webp'):
+        save_file = save_file + '.png'      # the reference would hand PIL an unknown suffix and fail; keep the image
+    pixels = ops.image_to_u8(tensor.to(torch.float32).contiguous(), min(value_range), max(value_range)).cpu().numpy()
+    error = None
+    for _ in range(retry):
+        try:
+            from PIL import Image
+            Image.fromarray(pixels).save(save_file)
+            return save_file
+        except Exception as e:  # noqa: BLE001  (the reference retries on any writer error)
+            error = e
+    logging.error(f'cache_image failed, error: {error}')
     return None
 
 

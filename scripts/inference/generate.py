@@ -28,7 +28,7 @@ sys.path.insert(0, os.path.join(ROOT, 'moviigen1.1_amd'))
 
 import wan  # noqa: E402
 from wan.configs import SIZE_CONFIGS, SUPPORTED_SIZES, WAN_CONFIGS  # noqa: E402
-from wan.utils.utils import cache_video, str2bool  # noqa: E402
+from wan.utils.utils import cache_image, cache_video, str2bool  # noqa: E402
 
 EXAMPLE_PROMPT = {   # one short default per task (the reference ships long showcase prompts here)
     't2v-14B': {'prompt': 'A cat walks on the grass, realistic style.'},
@@ -61,7 +61,7 @@ FLAGS = [
     ('--sample_guide_scale', dict(type=float, default=5.0, help='Classifier free guidance scale.')),
     # this engine's additions
     ('--cfg_parallel', dict(action='store_true', default=False,
-                            help='cond / uncond forwards on the two halves of the ranks (needs --ulysses_size == world size, even).')),
+                            help='cond / uncond forwards on the two halves of an even number of ranks, Ulysses inside each half (not with --ring_size > 1).')),
     ('--vae_parallel', dict(action='store_true', default=False, help='layer-pipelined VAE decode over all ranks.')),
     ('--prompt_embeds', dict(type=str, default=None, help="torch file {'prompt','negative'} of umT5 embeddings, replaces the text encoder.")),
 ]
@@ -163,9 +163,14 @@ def generate(args):
     if rank == 0:
         if args.save_file is None:
             args.save_file = default_save_name(args)
-        logging.info(f'Saving generated video to {args.save_file}')
-        args.saved_as = cache_video(tensor=video[None], save_file=args.save_file, fps=cfg.sample_fps, nrow=1,
-                                    normalize=True, value_range=(-1, 1))
+        if 't2i' in args.task:          # reference generate.py:308-315
+            logging.info(f'Saving generated image to {args.save_file}')
+            args.saved_as = cache_image(tensor=video.squeeze(1)[None], save_file=args.save_file, nrow=1,
+                                        normalize=True, value_range=(-1, 1))
+        else:
+            logging.info(f'Saving generated video to {args.save_file}')
+            args.saved_as = cache_video(tensor=video[None], save_file=args.save_file, fps=cfg.sample_fps, nrow=1,
+                                        normalize=True, value_range=(-1, 1))
     logging.info('Finished.')
     if dist.is_initialized():
         dist.barrier()

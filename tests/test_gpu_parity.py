@@ -275,6 +275,25 @@ def test_dit_full_width_vs_oracle(dev):
     assert rel_l2(out, ref32) < 2e-2                   # the stated bf16 tolerance against the fp32 algorithm
 
 
+def test_dit_hd128_padded_seq_len(dev):
+    """seq_len > the video's token count (reference model.py:534-538 pads x to seq_len and masks the padded keys,
+    attention.py k_lens): the packed-tile attention path must mask them too — 48 valid tokens inside seq_len 200
+    (1 key tile vs 4)."""
+    import wan
+    from oracle import dit
+    cfg = W.SMALL_DIT_HD128
+    P = W.make_dit_params(cfg, 0)
+    m = wan.modules.WanModel(**cfg)
+    m.load_state_dict(P)
+    m.to(dev)
+    lat, ctx, t = W.randn((16, 2, 8, 12), 20), W.randn((33, cfg['text_dim']), 30), torch.tensor([999])
+    out = m([lat.to(dev)], t=t.to(dev), context=[ctx.to(dev)], seq_len=200)[0]
+    ref = dit.dit_forward(P, cfg, lat, t, ctx, 200, emulate_bf16=True)
+    assert rel_l2(out, ref) < 1.2e-2
+    out48 = m([lat.to(dev)], t=t.to(dev), context=[ctx.to(dev)], seq_len=48)[0]
+    assert rel_l2(out, out48) < 1e-6          # padding never changes the video tokens
+
+
 def test_dit_context_cache_and_determinism(dev):
     import wan
     cfg = W.SMALL_DIT_HD128
@@ -461,6 +480,168 @@ def test_fullsize_gemm_properties(dev):
     assert torch.equal(x, 2 * x1)
 
 
+# ------------------------------------------------------------------------------------------------
+# BASELINE.json configs[2], [3], [4] at their sizes: per-rank attention / GEMM shapes of the Ulysses layouts
+# (cfg3 in SURVEY numbering = 1920x832x81f, L = 131 040, SP=8 -> 16 380 query rows x 131 040 keys x 5 heads;
+#  cfg4 = 1920x1056x81f, L = 166 320, SP=4 -> 41 580 x 166 320 x 10 heads), the single-GPU L = 131 040 launch
+# of the metric's configuration, and the 1920x832x81f VAE decode.
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('Lq,Lk,heads', [(16380, 131040, 5), (41580, 166320, 10), (131040, 131040, 40)],
+                         ids=['cfg1920x832_sp8_rank', 'cfg1920x1056_sp4_rank', 'cfg1920x832_single_gpu'])
+def test_fullsize_attention_big_configs(dev, Lq, Lk, heads):
+    from wan.backend import ops
+    gen = torch.Generator(device=dev).manual_seed(Lq % 97)
+    q = torch.randn(Lq, heads * 128, device=dev, generator=gen).bfloat16()
+    k = torch.randn(Lk, heads * 128, device=dev, generator=gen).bfloat16()
+    v = torch.randn(Lk, heads * 128, device=dev, generator=gen).bfloat16()
+    n_pk = ops.packed_kv_numel(Lk, heads)
+    kpk = torch.empty(n_pk, dtype=torch.bfloat16, device=dev)
+    vpk = torch.empty(n_pk, dtype=torch.bfloat16, device=dev)
+    o = torch.empty(Lq, heads * 128, dtype=torch.bfloat16, device=dev)
+    sc = 1 / math.sqrt(128)
+    # (1) softmax rows sum to one for EVERY query row and head: V = const => O = const
+    ops.pack_kv(k, torch.full_like(v, 0.5), heads, kpk, vpk)
+    ops.attention_hd128(q, kpk, vpk, o, Lk, heads, sc)
+    assert (o.float() - 0.5).abs().max().item() < 4e-3
+    # (2) sampled rows (first / last / tile edges / middle) vs fp32 softmax attention of the same bf16 data
+    ops.pack_kv(k, v, heads, kpk, vpk)
+    ops.attention_hd128(q, kpk, vpk, o, Lk, heads, sc)
+    rows = torch.tensor([0, 1, 63, 64, 255, 256, Lq // 2, Lq - 257, Lq - 2, Lq - 1], device=dev)
+    for h in sorted({0, heads // 2, heads - 1}):
+        qs = q[rows, h * 128:(h + 1) * 128].float()
+        s = (qs @ k[:, h * 128:(h + 1) * 128].float().T) * sc
+        ref = torch.softmax(s, -1) @ v[:, h * 128:(h + 1) * 128].float()
+        assert (o[rows, h * 128:(h + 1) * 128].float() - ref).abs().max().item() < 5e-3
+    # (3) a ragged key count (last 64-key tile partly filled) at this size
+    lk2 = Lk - 4097
+    ops.pack_kv(k[:lk2], v[:lk2], heads, kpk, vpk)
+    ops.attention_hd128(q, kpk, vpk, o, lk2, heads, sc)
+    qs = q[rows, :128].float()
+    ref = torch.softmax((qs @ k[:lk2, :128].float().T) * sc, -1) @ v[:lk2, :128].float()
+    assert (o[rows, :128].float() - ref).abs().max().item() < 5e-3
+
+
+@pytest.mark.parametrize('M', [16380, 41580, 131040])
+def test_fullsize_gemm_big_configs(dev, M):
+    """the four GEMM shapes of a block at the per-rank / single-GPU token counts of configs[2], [3]."""
+    from wan.backend import ops
+    d, f = 5120, 13824
+    gen = torch.Generator(device=dev).manual_seed(M % 89)
+    rows = torch.tensor([0, 127, 128, 255, 256, M // 2, M - 129, M - 1], device=dev)
+    for (N, K, epi) in ((3 * d, d, ops.BIAS_BF16), (f, d, ops.BIAS_GELU_BF16), (d, f, ops.GATE_RESID_F32), (d, d, ops.GATE_RESID_F32)):
+        a = torch.randn(M, K, device=dev, generator=gen).bfloat16()
+        w = (torch.randn(N, K, device=dev, generator=gen) * 0.02).bfloat16()
+        bias = torch.randn(N, device=dev, generator=gen) * 0.1
+        acc = a[rows].float() @ w.float().T + bias
+        if epi == ops.GATE_RESID_F32:
+            gate = torch.randn(N, device=dev, generator=gen)
+            x0 = torch.randn(M, N, device=dev, generator=gen)
+            x = x0.clone()
+            ops.gemm(a, w, bias, epi, x, gate=gate)
+            ref = x0[rows] + acc.bfloat16().float() * gate
+            assert ((x[rows] - ref).abs().max() / ref.abs().max()).item() < 1e-2
+            untouched = torch.tensor([1, M // 3, M - 2], device=dev)
+            assert not torch.equal(x[untouched], x0[untouched])           # every row got its update
+        else:
+            out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+            ops.gemm(a, w, bias, epi, out)
+            ref = torch.nn.functional.gelu(acc, approximate='tanh') if epi == ops.BIAS_GELU_BF16 else acc
+            assert ((out[rows].float() - ref).abs().max() / ref.abs().max()).item() < 1e-2
+        del a, w
+
+
+def _conv_ref_f64(x, cache, w, bias, pts, up2=False):
+    """direct fp64 evaluation of the causal 3x3x3 / 3x3 convolution (reference vae.py:17-36; nearest-2x first when
+    up2, vae.py:57-63) at sampled output voxels.  x [T,H,W,Ci], cache [Tc,H,W,Ci] or None, w [Co,kt,kh,kw,Ci]."""
+    Co, kt, kh, kw, Ci = w.shape
+    T, H, W, _ = x.shape
+    Ho, Wo = (2 * H, 2 * W) if up2 else (H, W)
+    tc = 0 if cache is None else cache.shape[0]
+    wd = w.double().cpu()
+    out = []
+    for (t, y, xx) in pts:
+        acc = bias.double().cpu().clone()
+        for a in range(kt):
+            ts = t - (kt - 1) + a                       # causal: taps reach back in time only
+            if ts < -tc:
+                continue                                # zero left padding
+            src = x[ts] if ts >= 0 else cache[tc + ts]
+            for b in range(kh):
+                for c in range(kw):
+                    yy, xc = y + b - kh // 2, xx + c - kw // 2
+                    if yy < 0 or yy >= Ho or xc < 0 or xc >= Wo:
+                        continue
+                    vec = src[yy // 2, xc // 2] if up2 else src[yy, xc]
+                    acc += wd[:, a, b, c, :] @ vec.double().cpu()
+        out.append(acc)
+    return torch.stack(out)
+
+
+@pytest.mark.parametrize('cin,cout,H,W,up2,kt', [(96, 96, 832, 1920, False, 3), (192, 192, 416, 960, False, 3),
+                                                 (192, 96, 416, 960, True, 1), (96, 3, 832, 1920, False, 3)],
+                         ids=['res96_832x1920', 'res192_416x960', 'up192to96_2x', 'head96to3'])
+def test_fullsize_vae_conv_config5(dev, cin, cout, H, W, up2, kt):
+    """the last decoder stages of the 1920x832 decode (BASELINE configs[4]) at their real spatial size: one frame
+    with a 2-frame causal cache, sampled output voxels (corners, edges, interior) vs a direct fp64 evaluation."""
+    from wan.backend import ops
+    gen = torch.Generator(device=dev).manual_seed(cin + cout)
+    x = torch.randn(1, H, W, cin, device=dev, generator=gen)
+    cache = torch.randn(2, H, W, cin, device=dev, generator=gen) if kt == 3 else None
+    w = torch.randn(cout, kt, 3, 3, cin, device=dev, generator=gen) / math.sqrt(kt * 9 * cin)
+    b = torch.randn(cout, device=dev, generator=gen)
+    Ho, Wo = (2 * H, 2 * W) if up2 else (H, W)
+    out = torch.empty(1, Ho, Wo, cout, device=dev)
+    ops.vae_conv(x, w, b, out, kt, 3, 3, cache=cache, up2=up2)
+    pts = [(0, 0, 0), (0, 0, Wo - 1), (0, Ho - 1, 0), (0, Ho - 1, Wo - 1), (0, 1, 1), (0, Ho // 2, Wo // 2),
+           (0, Ho // 2 + 1, Wo - 1), (0, 255, 256), (0, Ho - 2, 63), (0, 17, Wo - 2)]
+    ref = _conv_ref_f64(x, cache, w, b, pts, up2)
+    got = torch.stack([out[t, y, xx] for (t, y, xx) in pts]).double().cpu()
+    assert ((got - ref).abs().max() / ref.abs().max()).item() < 1e-5
+    assert torch.isfinite(out).all().item()
+
+
+def test_fullsize_vae_decode_config5(dev):
+    """BASELINE configs[4]: the 1920x832x81f decode (latent [16,21,104,240], seed 7) through WanVAE.decode:
+    shape / finite / range, and two size-independent properties of the causal decoder — the first 17 output frames
+    depend on the first 5 latent frames only (causality, vae.py:17-36), and the chunking of the latent frames is
+    free — checked at the full spatial size."""
+    import wan
+    vae = wan.modules.WanVAE(state_dict=W.make_vae_params(96, 1), device=dev)
+    z = torch.randn(16, 21, 104, 240, generator=torch.Generator().manual_seed(7)).to(dev)
+    video = vae.decode([z])[0]
+    assert video.shape == (3, 81, 832, 1920) and video.dtype == torch.float32
+    assert torch.isfinite(video).all().item() and video.abs().max().item() <= 1.0
+    assert video.std().item() > 1e-3
+    head = vae.model.decode(z[:, :5].contiguous())
+    assert torch.equal(head, video[:, :17])                       # causal, and the same launches -> bit-equal
+    del video
+    rechunk = vae.model.decode(z[:, :5].contiguous(), chunks=[1, 2, 2])
+    assert (rechunk - head).abs().max().item() < 1e-5
+
+
+def test_dit_depth40_vs_oracle(dev):
+    """error growth over the real DEPTH: 40 layers (dim 1024, 8 heads x 128, ffn 2048, 512 tokens) against the
+    bf16-emulating oracle and against the fp32 algorithm — the stated bf16 tolerance (rel-L2 <= 2e-2) must hold at
+    40 layers, not only at 2 (the bf16 rounding model itself sits 4.7e-3 from fp32 here)."""
+    import wan
+    from oracle import dit
+    cfg = dict(model_type='t2v', patch_size=(1, 2, 2), text_len=64, in_dim=16, dim=1024, ffn_dim=2048, freq_dim=256,
+               text_dim=128, out_dim=16, num_heads=8, num_layers=40, eps=1e-6)
+    P = W.make_dit_params(cfg, 5)
+    m = wan.modules.WanModel(**cfg)
+    m.load_state_dict(P)
+    m.to(dev)
+    lat = W.randn((16, 2, 32, 32), 21)
+    ctx = W.randn((40, 128), 22)
+    t = torch.tensor([417.0])
+    out = m([lat.to(dev)], t=t.to(dev), context=[ctx.to(dev)], seq_len=512)[0]
+    orc = dit.dit_forward(P, cfg, lat, t, ctx, 512, emulate_bf16=True)
+    ref32 = dit.dit_forward(P, cfg, lat, t, ctx, 512, emulate_bf16=False)
+    e_bf, e_32 = rel_l2(out, orc), rel_l2(out, ref32)
+    print(f'depth-40 rel-L2: vs bf16 oracle {e_bf:.3e}, vs fp32 {e_32:.3e}')
+    assert e_bf < 1.2e-2 and e_32 < 2e-2
+
+
 def test_sequence_parallel_two_ranks_one_gpu():
     """Ulysses path end to end with world_size 2 (both ranks on cuda:0, gloo transport):
     sharded forward == unsharded forward, bit for bit."""
@@ -548,6 +729,22 @@ def test_video_write_out(dev, tmp_path):
     assert torch.equal(got.cpu(), ref)
     path = cache_video(v.to(dev)[None], save_file=str(tmp_path / 'out.mp4'))
     assert path is not None and (path.endswith('.mp4') or (path.endswith('.npy') and np.array_equal(np.load(path), ref.numpy())))
+
+
+def test_image_write_out(dev, tmp_path):
+    """t2i result -> PNG: the reference's cache_image (utils.py:64-91 = torchvision save_image: x255, +0.5, clamp,
+    uint8), byte for byte, and the file really holds those pixels."""
+    from PIL import Image
+    from wan.utils.utils import cache_image
+    img = (W.randn((3, 1, 20, 36), 78) * 0.8)                    # generate() returns [3, 1, H, W] for t2i
+    img[0, 0, 0, :4] = torch.tensor([1.0, -1.0, 1.7, -3.0])
+    x = img.squeeze(1).clamp(-1, 1)
+    x = (x - (-1)) / max(1 - (-1), 1e-5)
+    ref = x.mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to(torch.uint8)
+    path = cache_image(tensor=img.to(dev).squeeze(1)[None], save_file=str(tmp_path / 'out.png'), nrow=1,
+                       normalize=True, value_range=(-1, 1))
+    assert path is not None and path.endswith('.png')
+    assert np.array_equal(np.asarray(Image.open(path)), ref.numpy())
 
 
 @pytest.mark.parametrize('world', [2, 3])
@@ -639,7 +836,7 @@ def test_bench_multirank_code_path(world, extra):
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
-              'vs_baseline', 'dtype', 'data', 'config', 'roofline'):
+              'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'sec_per_video', 'vae_decode'):
         assert k in d, k
     assert d['n_gpus'] == world and d['scaling'] == 'strong' and d['value'] > 0
     want = f'ulysses_sp{world}' if extra else (f'cfg2 x ulysses_sp{world // 2}')

@@ -222,3 +222,25 @@ def test_tokenizer_cleaning_modes():
             assert tok._prepare(text) == want, (mode, text)
     with pytest.raises(AssertionError):
         HuggingfaceTokenizer('x', clean='bogus')
+
+
+def test_tokenizer_ftfy_defaults_restated():
+    """ftfy.fix_text's default fixes that touch well-formed prompts (reference tokenizers.py:13), restated because ftfy is
+    not in this image: the default negative prompt's fullwidth commas become ',', as ftfy's fix_character_width does
+    (so umT5 sees the ids the reference sees), quotes are uncurled, ligatures expanded, line breaks unified, control
+    characters and terminal escapes removed.  Expected strings are ftfy 6's documented outputs for these inputs."""
+    from wan.configs import WAN_CONFIGS
+    from wan.modules import tokenizers as tk
+    neg = WAN_CONFIGS['t2v-14B'].sample_neg_prompt
+    assert '，' in neg
+    got = tk.clean_text(neg, 'whitespace')
+    assert got == neg.replace('，', ',') and '，' not in got
+    rows = [('“quote” and ‘single’', '"quote" and \'single\''),
+            ('ﬁne ﬂow', 'fine flow'),
+            ('ＡＢＣ　１２！', 'ABC 12!'),
+            ('a\r\nb\rc d', 'a b c d'),
+            ('x\x07y﻿z', 'xyz'),
+            ('\x1b[31mred\x1b[0m', 'red'),
+            ('é', 'é')]
+    for text, want in rows:
+        assert tk.clean_text(text, 'whitespace') == want, ascii(text)
