@@ -121,6 +121,34 @@ int mg_attn_fwd_bf16_hd128_lse(const uint16_t* q, int64_t ldq, const uint16_t* k
                                uint16_t* o, int64_t ldo, float* lse, int64_t Lq, int64_t Lk, int heads,
                                float scale, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Ulysses sequence-parallel exchange layouts (the transposes xfuser / FastVideo's all_to_all_4D do
+ * around their all-to-alls: wan/distributed/xdit_context_parallel.py:185-190,
+ * scripts/train/model/model_seq.py:232-234,256).  The collective itself is issued by the host
+ * (RCCL all_to_all_single on a communication stream); these two kernels produce / consume its
+ * contiguous buffers so that ONE exchange carries q, k and v of a head group.
+ * ---------------------------------------------------------------------------------------- */
+
+/* send[p][t][i*w + c] = x_i[t][p*cols_per_dest + col0 + c]   (i = 0,1,2 for q,k,v; p < P; t < Lloc; c < w)
+ *   q, k, v: [Lloc][>= P*cols_per_dest] bf16, row strides ldq/ldk/ldv (column slices of a fused buffer are fine)
+ *   cols_per_dest = (heads / P) * head_dim; [col0, col0 + w) = the head group inside a destination's slice.
+ * After all_to_all_single(recv, send) the receive buffer is the row-major [P*Lloc][3w] matrix of ALL tokens
+ * (rank order) x (q | k | v) of this rank's heads of the group.  All widths/strides % 8 == 0, 16-byte aligned. */
+int mg_sp_pack_qkv_bf16(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk, const uint16_t* v,
+                        int64_t ldv, int64_t Lloc, int P, int cols_per_dest, int col0, int w, uint16_t* send,
+                        void* stream);
+
+/* the way back: recv[p][t][c] (attention output of source rank p's heads for MY tokens) ->
+ * o[t][p*cols_per_src + col0 + c], o row stride ldo. */
+int mg_sp_unpack_o_bf16(const uint16_t* recv, int64_t Lloc, int P, int cols_per_src, int col0, int w, uint16_t* o,
+                        int64_t ldo, void* stream);
+
+/* the strided block copy both are built on (one-tensor seq<->head exchanges, all_to_all_4D's reshape):
+ * dst[b*d_blk + r*d_row + c] = src[b*s_blk + r*s_row + c], b < blocks, r < rows, c < width; strides in elements,
+ * everything % 8 == 0, 16-byte aligned. */
+int mg_sp_copy_blocks_bf16(const uint16_t* src, int64_t s_blk, int64_t s_row, uint16_t* dst, int64_t d_blk,
+                           int64_t d_row, int blocks, int64_t rows, int width, void* stream);
+
 /* Ring attention (the reference delegates to yunchang inside xFuserLongContextAttention,
  * generate.py:225-229): fold one block's normalised bf16 result `part` [Lq][heads*128] and its lse into
  * the running fp32 result: lse' = logaddexp(lse, lse_j), acc' = acc*exp(lse-lse') + part*exp(lse_j-lse').

@@ -520,11 +520,12 @@ int main(int argc, char** argv) {
     }
     if (argc > 1 && !strcmp(argv[1], "gemmshapes")) {   // the five GEMMs of a DiT block at 720p, with their epilogues
         mg_gemm_set_variant(argc > 2 ? atoi(argv[2]) : 5);
-        test_gemm(75600, 15360, 5120, 0, 128, true);     // q|k|v
-        test_gemm(75600, 5120, 5120, 2, 128, true);      // self-attention o (+ gate, residual)
-        test_gemm(75600, 5120, 5120, 0, 128, true);      // cross-attention q
-        test_gemm(75600, 13824, 5120, 1, 128, true);     // ffn.0 + GELU
-        test_gemm(75600, 5120, 13824, 2, 128, true);     // ffn.2 (+ gate, residual)
+        const int64_t Mg = argc > 3 ? atoll(argv[3]) : 75600;   // 131040 = the 1920x832x81f token count
+        test_gemm(Mg, 15360, 5120, 0, 128, true);     // q|k|v
+        test_gemm(Mg, 5120, 5120, 2, 128, true);      // self-attention o (+ gate, residual)
+        test_gemm(Mg, 5120, 5120, 0, 128, true);      // cross-attention q
+        test_gemm(Mg, 13824, 5120, 1, 128, true);     // ffn.0 + GELU
+        test_gemm(Mg, 5120, 13824, 2, 128, true);     // ffn.2 (+ gate, residual)
         return n_fail ? 1 : 0;
     }
     if (argc > 1 && !strcmp(argv[1], "gemmprof")) {  // s_memtime breakdown of the 256x128 GEMM k-loop

@@ -239,6 +239,36 @@ def video_to_u8(video, lo=-1.0, hi=1.0):
     return out
 
 
+def sp_pack_qkv(q, k, v, P, cols_per_dest, col0, w, send):
+    """q, k, v [Lloc, >= P*cols_per_dest] bf16 (column slices ok) -> send [P, Lloc, 3w] (see moviigen_hip.h)."""
+    for n, t in (('q', q), ('k', k), ('v', v), ('send', send)):
+        _chk(t, torch.bfloat16, n)
+    Lloc = q.shape[0]
+    if send.numel() < P * Lloc * 3 * w or not send.is_contiguous():
+        raise lib.MoviigenHipError('send buffer too small / not contiguous')
+    lib.call('mg_sp_pack_qkv_bf16', _p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), Lloc, int(P),
+             int(cols_per_dest), int(col0), int(w), _p(send), _st())
+    return send
+
+
+def sp_unpack_o(recv, P, cols_per_src, col0, w, o):
+    """recv [P, Lloc, w] bf16 -> o[:, p*cols_per_src + col0 : +w] for every source rank p."""
+    _chk(recv, torch.bfloat16, 'recv'); _chk(o, torch.bfloat16, 'o')
+    Lloc = o.shape[0]
+    if recv.numel() < P * Lloc * w or not recv.is_contiguous():
+        raise lib.MoviigenHipError('recv buffer too small / not contiguous')
+    lib.call('mg_sp_unpack_o_bf16', _p(recv), Lloc, int(P), int(cols_per_src), int(col0), int(w), _p(o), o.stride(0), _st())
+    return o
+
+
+def sp_copy_blocks(src, s_blk, s_row, dst, d_blk, d_row, blocks, rows, width):
+    """dst[b][r][:width] = src[b][r][:width] with element strides (*_blk, *_row): the reshapes around an all-to-all."""
+    _chk(src, torch.bfloat16, 'src'); _chk(dst, torch.bfloat16, 'dst')
+    lib.call('mg_sp_copy_blocks_bf16', _p(src), int(s_blk), int(s_row), _p(dst), int(d_blk), int(d_row), int(blocks),
+             int(rows), int(width), _st())
+    return dst
+
+
 def image_to_u8(image, lo=-1.0, hi=1.0):
     """[3,H,W] fp32 -> uint8 pixels [H,W,3] (reference cache_image / torchvision save_image arithmetic: rounds)."""
     _chk(image, torch.float32, 'image')

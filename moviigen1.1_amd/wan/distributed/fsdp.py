@@ -36,7 +36,9 @@ class BlockShards:
     def __init__(self, model, group=None, sync_module_states=True):
         if not dist.is_initialized():
             raise RuntimeError('torch.distributed is not initialised (launch with torchrun, one process per GPU)')
-        self.group = group if group is not None else dist.group.WORLD
+        # an OWN communicator over the ranks (a second RCCL comm = its own stream): the prefetch gathers then overlap
+        # the attention all-to-alls instead of queueing behind them on the WORLD communicator
+        self.group = group if group is not None else dist.new_group(list(range(dist.get_world_size())))
         self.P = dist.get_world_size(self.group)
         self.rank = dist.get_rank(self.group)
         self.staged = dist.get_backend(self.group) == 'gloo'

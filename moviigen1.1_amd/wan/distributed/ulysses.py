@@ -5,19 +5,35 @@ The reference delegates this to un-vendored libraries: xfuser's xFuserLongContex
 (wan/distributed/xdit_context_parallel.py:185-190) and FastVideo's all_to_all_4D
 (scripts/train/model/model_seq.py:232-234,256).  Semantics:
 
-  seq_to_head : [L/P tokens, N heads]   -> [L tokens, N/P heads]   (q, k, v before attention)
-  head_to_seq : [L tokens, N/P heads]   -> [L/P tokens, N heads]   (attention output)
+  seq -> head : [L/P tokens, N heads]   -> [L tokens, N/P heads]   (q, k, v before attention)
+  head -> seq : [L tokens, N/P heads]   -> [L/P tokens, N heads]   (attention output)
   all_gather_seq : rank-order concatenation along tokens            (head output, once/forward)
 
-All three are single collectives on contiguous buffers (all_to_all_single / all_gather_into_tensor):
-on the fully connected xGMI mesh an all-to-all sends each peer its 1/P slice over its own direct
-link, all 7 links concurrently.  Tokens are sharded contiguously: rank r owns [r*L/P, (r+1)*L/P).
+`HeadExchange` is what WanModel runs per layer: the rank's heads are cut into G head groups and
+the layer becomes a software pipeline over them —
 
-`gloo` with CUDA tensors (the 2-process test on a 1-GPU box) is staged through host memory —
-test plumbing only; production is RCCL, device to device.
+    compute stream :  pack(0..G-1) | attn(0)      | attn(1)      | ... | unpack(0..G-1)
+    comm stream    :    qkv a2a(0) qkv a2a(1) ... | o a2a(0)     | o a2a(1) ...
+
+  * ONE packed exchange per group carries q, k and v (mg_sp_pack_qkv_bf16 writes the
+    [dest][token][q|k|v] send layout straight from the fused qkv activations; the receive buffer is
+    then directly the row-major [L][3w] operand matrix — no transposes, no unpack on that side);
+  * all buffers are persistent (allocated once per shape), nothing is allocated inside the layer loop;
+  * collectives are issued on a dedicated HIP stream and ordered against the kernels with events, so
+    the exchange of group g+1 and the return of group g-1 run under the attention of group g.
+    On the fully connected xGMI mesh an all-to-all sends each peer its 1/P slice over its own direct
+    link, all 7 links concurrently.  Tokens are sharded contiguously: rank r owns [r*L/P, (r+1)*L/P).
+
+`gloo` with CUDA tensors (the multi-process tests on a 1-GPU box) is staged through host memory —
+test plumbing only; production is RCCL, device to device.  `seq_to_head` / `head_to_seq` keep the
+one-tensor call shape of the reference libraries (used by the training-side SP forward and tests).
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+from ..backend import ops
 
 
 def _a2a(recv, send, group):
@@ -29,11 +45,83 @@ def _a2a(recv, send, group):
         dist.all_to_all_single(recv, send, group=group)
 
 
+def split_heads(n_loc, max_groups):
+    """[(first local head, heads)] of the pipeline groups: sizes differ by at most one."""
+    G = max(1, min(int(n_loc), int(max_groups)))
+    base, extra = divmod(n_loc, G)
+    out, h0 = [], 0
+    for g in range(G):
+        n = base + (1 if g < extra else 0)
+        out.append((h0, n))
+        h0 += n
+    return out
+
+
+class HeadExchange:
+    """persistent buffers, events and the communication stream of the pipelined exchange for one
+    (group, Lloc) shape.  `run(q, k, v, out, attend)` executes one layer's exchange + attention."""
+
+    def __init__(self, group, P, heads, head_dim, Lloc, device, max_groups=None):
+        if heads % P:
+            raise ValueError(f'`num_heads` {heads} cannot be divided evenly by the sequence-parallel size {P}')
+        if max_groups is None:
+            max_groups = int(os.environ.get('MOVIIGEN_SP_GROUPS', '5'))
+        self.group, self.P, self.hd, self.Lloc = group, P, head_dim, Lloc
+        self.n_loc = heads // P
+        self.cols = self.n_loc * head_dim                      # columns of one destination's head slice
+        self.groups = split_heads(self.n_loc, max_groups)
+        bf = torch.bfloat16
+        e = lambda *s: torch.empty(*s, dtype=bf, device=device)  # noqa: E731
+        self.send, self.recv, self.ag, self.orecv = [], [], [], []
+        for _, n in self.groups:
+            w = n * head_dim
+            self.send.append(e(P, Lloc, 3 * w))
+            self.recv.append(e(P * Lloc, 3 * w))
+            self.ag.append(e(P * Lloc, w))
+            self.orecv.append(e(P, Lloc, w))
+        self.comm = torch.cuda.Stream(device=device)
+        ev = lambda: [torch.cuda.Event() for _ in self.groups]  # noqa: E731
+        self.ev_pack, self.ev_recv, self.ev_attn, self.ev_o = ev(), ev(), ev(), ev()
+
+    def run(self, q, k, v, out, attend):
+        """q, k, v: [Lloc, heads*hd] bf16 (column slices of the fused qkv buffer are fine); out [Lloc, heads*hd].
+        attend(qg, kg, vg, ag, n_heads): attention of n_heads heads over ALL tokens of the group, operands are
+        column views (row stride 3w) of the receive buffer, ag a contiguous [P*Lloc, w] result buffer."""
+        P, hd, cur = self.P, self.hd, torch.cuda.current_stream()
+        for g, (h0, n) in enumerate(self.groups):
+            ops.sp_pack_qkv(q, k, v, P, self.cols, h0 * hd, n * hd, self.send[g])
+            self.ev_pack[g].record(cur)
+        with torch.cuda.stream(self.comm):
+            for g in range(len(self.groups)):
+                self.comm.wait_event(self.ev_pack[g])
+                _a2a(self.recv[g].view(P, self.Lloc, -1), self.send[g], self.group)
+                self.ev_recv[g].record(self.comm)
+        for g, (h0, n) in enumerate(self.groups):
+            w = n * hd
+            cur.wait_event(self.ev_recv[g])
+            r = self.recv[g]
+            attend(r[:, :w], r[:, w:2 * w], r[:, 2 * w:], self.ag[g], n)
+            self.ev_attn[g].record(cur)
+            with torch.cuda.stream(self.comm):
+                self.comm.wait_event(self.ev_attn[g])
+                _a2a(self.orecv[g], self.ag[g].view(P, self.Lloc, w), self.group)
+                self.ev_o[g].record(self.comm)
+        for g, (h0, n) in enumerate(self.groups):
+            cur.wait_event(self.ev_o[g])
+            ops.sp_unpack_o(self.orecv[g], P, self.cols, h0 * hd, n * hd, out)
+        return out
+
+
+# ---- one-tensor exchanges in the call shape of the reference libraries ----------------------------
 def seq_to_head(x, out, group, P, heads, head_dim):
     """x [Lloc, heads*hd] (row stride free) -> out [P*Lloc, (heads/P)*hd], tokens in rank order."""
     Lloc = x.shape[0]
     nl = (heads // P) * head_dim
-    send = x.reshape(Lloc, P, nl).transpose(0, 1).contiguous()      # [dest rank][token][local heads]
+    if x.is_cuda:
+        send = torch.empty(P, Lloc, nl, dtype=x.dtype, device=x.device)
+        ops.sp_copy_blocks(x, nl, x.stride(0), send, Lloc * nl, nl, P, Lloc, nl)
+    else:        # CPU tensors: host-side index plumbing of the gloo tests (no arithmetic)
+        send = x.reshape(Lloc, P, nl).transpose(0, 1).contiguous()
     _a2a(out.view(P, Lloc, nl), send, group)
     return out
 
@@ -44,7 +132,10 @@ def head_to_seq(x, out, group, P, heads, head_dim):
     Lloc = x.shape[0] // P
     recv = torch.empty(P, Lloc, nl, dtype=x.dtype, device=x.device)  # [source rank = head group][token][..]
     _a2a(recv, x.view(P, Lloc, nl), group)
-    out.view(Lloc, P, nl).copy_(recv.transpose(0, 1))
+    if x.is_cuda:
+        ops.sp_copy_blocks(recv, Lloc * nl, nl, out, nl, out.stride(0), P, Lloc, nl)
+    else:
+        out.view(Lloc, P, nl).copy_(recv.transpose(0, 1))
     return out
 
 

@@ -284,12 +284,15 @@ class WanModel(nn.Module):
                       mod=e(6 * self.num_layers, d, dt=f32), hmod=e(2, d, dt=f32))
             U, R = self._sp_layout()
             n_loc, Lg = self.num_heads // U, L * U          # heads and tokens a rank attends after the Ulysses exchange
+            n_att = n_loc
+            if U > 1 or self.sp_force:     # pipelined packed exchange (wan/distributed/ulysses.py): buffers live there
+                from ..distributed.ulysses import HeadExchange
+                ug = self.uly_group if self.uly_group is not None else self.sp_group
+                ws['xchg'] = HeadExchange(ug, U, self.num_heads, hd, L, dev, max_groups=1 if R > 1 else None)
+                n_att = max(n for _, n in ws['xchg'].groups)
             if hd == 128 and R == 1:   # K / V packed into 64-key tiles (operand layout of the MFMA attention kernel)
-                n_pk = ops.packed_kv_numel(Lg, n_loc)
+                n_pk = ops.packed_kv_numel(Lg, n_att)
                 ws['kp'], ws['vp'] = e(n_pk), e(n_pk)
-            if U > 1 or self.sp_force:
-                ws['qg'], ws['kg'], ws['vg'] = e(Lg, n_loc * hd), e(Lg, n_loc * hd), e(Lg, n_loc * hd)
-                ws['ag'] = e(Lg, n_loc * hd)
             if R > 1:                  # ring attention: two packed K/V blocks in flight, fp32 running result
                 n1 = ops.packed_kv_numel(Lg, n_loc)
                 ws['kp0'], ws['vp0'], ws['kp1'], ws['vp1'] = e(n1), e(n1), e(n1), e(n1)
@@ -309,12 +312,14 @@ class WanModel(nn.Module):
     # 168-170) — independent of t, so done once per prompt tensor and cached
     # ------------------------------------------------------------------------------------------
     def _context(self, ctx):
+        """-> (ctx, emb [text_len, dim] bf16, layers): `layers[i]` is block i's cross-attention (K, V) — filled by
+        _cross_kv the first time block i runs for this prompt, i.e. while that block's weights are at hand anyway
+        (block-sharded mode: no extra all-gather sweep over the 28 GB of weights per new prompt)."""
         key = (ctx.data_ptr(), tuple(ctx.shape), ctx._version)
         hit = self._ctx_cache.get(key)
         if hit is not None:
             return hit
-        pk = self._pack()
-        dev, d, hd = ctx.device, self.dim, self.dim // self.num_heads
+        dev, d = ctx.device, self.dim
         Lc = self.text_len
         bf = torch.bfloat16
         pad = torch.zeros(Lc, self.text_dim, dtype=bf, device=dev)
@@ -324,24 +329,25 @@ class WanModel(nn.Module):
         te = self.text_embedding
         ops.gemm(pad, te['0'].weight, te['0'].bias, ops.BIAS_GELU_BF16, t0)
         ops.gemm(t0, te['2'].weight, te['2'].bias, ops.BIAS_BF16, emb)
-        kv = torch.empty(Lc, 2 * d, dtype=bf, device=dev)
-        layers = []
-        for li, b in enumerate(self.blocks):
-            lw = self._layer(li)
-            ops.gemm(emb, lw['wkv_c'], lw['bkv_c'], ops.BIAS_BF16, kv)
-            kc = torch.empty(Lc, d, dtype=bf, device=dev)
-            ops.rmsnorm_rope(kv[:, :d], b.cross_attn.norm_k.weight, self.eps, hd, kc)
-            if hd == 128:
-                n_pk = ops.packed_kv_numel(Lc, self.num_heads)
-                kcp, vcp = torch.empty(n_pk, dtype=bf, device=dev), torch.empty(n_pk, dtype=bf, device=dev)
-                ops.pack_kv(kc, kv[:, d:], self.num_heads, kcp, vcp)
-                layers.append((kcp, vcp))
-            else:
-                layers.append((kc, kv[:, d:].clone()))
         if len(self._ctx_cache) >= 4:
             self._ctx_cache.pop(next(iter(self._ctx_cache)))
-        self._ctx_cache[key] = (ctx, layers)  # keep ctx alive so data_ptr stays unique
+        self._ctx_cache[key] = (ctx, emb, [None] * self.num_layers)  # keep ctx alive so data_ptr stays unique
         return self._ctx_cache[key]
+
+    def _cross_kv(self, i, lw, emb):
+        """cross-attention K (RMS-normed) and V of block i for one prompt (reference model.py:168-170)."""
+        dev, d, hd = emb.device, self.dim, self.dim // self.num_heads
+        Lc, bf = self.text_len, torch.bfloat16
+        kv = torch.empty(Lc, 2 * d, dtype=bf, device=dev)
+        ops.gemm(emb, lw['wkv_c'], lw['bkv_c'], ops.BIAS_BF16, kv)
+        kc = torch.empty(Lc, d, dtype=bf, device=dev)
+        ops.rmsnorm_rope(kv[:, :d], self.blocks[i].cross_attn.norm_k.weight, self.eps, hd, kc)
+        if hd == 128:
+            n_pk = ops.packed_kv_numel(Lc, self.num_heads)
+            kcp, vcp = torch.empty(n_pk, dtype=bf, device=dev), torch.empty(n_pk, dtype=bf, device=dev)
+            ops.pack_kv(kc, kv[:, d:], self.num_heads, kcp, vcp)
+            return kcp, vcp
+        return kc, kv[:, d:].clone()
 
     # ------------------------------------------------------------------------------------------
     def _attention(self, q, k, v, out, lk, heads):
@@ -368,28 +374,28 @@ class WanModel(nn.Module):
             else:
                 self._attention(ws['q'], ws['k'], qkv[:, 2 * d:], ws['a'], self._kv_valid, N)
             return
-        from ..distributed import ulysses
         U, R = self._sp_layout()
-        ug = self.uly_group if self.uly_group is not None else self.sp_group
         rg = self.ring_group if self.ring_group is not None else self.sp_group
         rr = self.ring_rank if self.uly_size is not None else self.sp_rank
-        n_loc, Lg = N // U, L * U
+        scale = 1.0 / math.sqrt(hd)
         q, k, v, a = ws['q'], ws['k'], qkv[:, 2 * d:], ws['a']
-        if U > 1 or self.sp_force:          # Ulysses: tokens of the group, heads / U
-            ulysses.seq_to_head(q, ws['qg'], ug, U, N, hd)
-            ulysses.seq_to_head(k, ws['kg'], ug, U, N, hd)
-            ulysses.seq_to_head(v, ws['vg'], ug, U, N, hd)
-            q, k, v, a = ws['qg'], ws['kg'], ws['vg'], ws['ag']
-        if R > 1:                           # ring attention across the groups (hd 128 only)
-            from ..distributed.ring import ring_attention
-            ring_attention(q, k, v, a, ws, rg, R, rr, n_loc, 1.0 / math.sqrt(hd))
-        elif hd == 128:
-            ops.pack_kv(k, v, n_loc, ws['kp'], ws['vp'])
-            self._attention(q, ws['kp'], ws['vp'], a, Lg, n_loc)
-        else:
-            self._attention(q, k, v, a, Lg, n_loc)
+
+        def attend(qg, kg, vg, ag, heads):      # operands may be strided column views; ag contiguous
+            if R > 1:                           # ring attention across the groups (hd 128 only)
+                from ..distributed.ring import ring_attention
+                ring_attention(qg, kg, vg, ag, ws, rg, R, rr, heads, scale)
+            elif hd == 128:
+                ops.pack_kv(kg, vg, heads, ws['kp'], ws['vp'])
+                ops.attention_hd128(qg, ws['kp'], ws['vp'], ag, kg.shape[0], heads, scale)
+            else:
+                ops.attention_generic(qg, kg, vg, ag, kg.shape[0], heads, hd, scale)
+
         if U > 1 or self.sp_force:
-            ulysses.head_to_seq(ws['ag'], ws['a'], ug, U, N, hd)
+            # Ulysses: packed q|k|v exchange per head group on the comm stream, pipelined against the attention
+            # launches (xdit_context_parallel.py:185-190 / model_seq.py:232-256)
+            ws['xchg'].run(q, k, v, a, attend)
+        else:                                   # pure ring: every rank keeps all heads
+            attend(q, k, v, a, N)
 
     @torch.no_grad()
     def _forward_one(self, lat, t, ctx, seq_len):
@@ -436,7 +442,7 @@ class WanModel(nn.Module):
         ops.add_rows(pk['modulation'], ws['e0'], ws['mod'], 6)                       # model.py:292-295
         ops.add_rows(self.head.modulation.data.reshape(2, d), ws['e'].reshape(1, d), ws['hmod'], 1)
 
-        _, ctx_layers = self._context(ctx)
+        _, ctx_emb, ctx_layers = self._context(ctx)
         rope = self._rope_tab(grid, dev)
         mod = ws['mod']
 
@@ -450,6 +456,8 @@ class WanModel(nn.Module):
             ops.gemm(ws['a'], lw['self_attn.o'], blk.self_attn.o.bias, ops.GATE_RESID_F32, x, gate=m[2])
             # cross attention (text keys/values cached per prompt)
             ca = blk.cross_attn
+            if ctx_layers[i] is None:          # first forward with this prompt
+                ctx_layers[i] = self._cross_kv(i, lw, ctx_emb)
             kc, vc = ctx_layers[i]
             ops.ln_modulate(x, blk.norm3.weight, blk.norm3.bias, False, eps, ws['h'])
             ops.gemm(ws['h'], lw['cross_attn.q'], ca.q.bias, ops.BIAS_BF16, ws['q'])

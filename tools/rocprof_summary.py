@@ -27,7 +27,7 @@ def main():
         big = [x for x in d if x > 10000]
         small = [x for x in d if x <= 10000]
         if big:
-            lines.append(f'# mg_attn_fwd_bf16_hd128 self-attention launches (75 600 keys) : n={len(big)} avg_us={sum(big)/len(big):.1f}')
+            lines.append(f'# mg_attn_fwd_bf16_hd128 self-attention launches (all video keys): n={len(big)} avg_us={sum(big)/len(big):.1f}')
         if small:
             lines.append(f'# mg_attn_fwd_bf16_hd128 cross-attention launches (512 keys)   : n={len(small)} avg_us={sum(small)/len(small):.1f}')
     except sqlite3.Error as e:  # schema differences between rocprofv3 versions
