@@ -121,6 +121,13 @@ int mg_attn_fwd_bf16_hd128_lse(const uint16_t* q, int64_t ldq, const uint16_t* k
                                uint16_t* o, int64_t ldo, float* lse, int64_t Lq, int64_t Lk, int heads,
                                float scale, void* stream);
 
+/* x[r][c] += float(y[r][c]) * gate[c]: the gated residual update of wan/modules/model.py:301-302,306,308-309 as a
+ * stand-alone kernel (x fp32 [rows][dim] row stride ldx; y bf16 row stride ldy; gate fp32 [dim] or NULL = 1).
+ * The fused form is MG_EPI_GATE_RESID_F32; this one serves a caller-replaced attention operator
+ * (`types.MethodType(fn, block.self_attn)`, wan/text2video.py:97-100).  dim, ldx, ldy % 4 == 0. */
+int mg_gate_residual_f32(float* x, int64_t ldx, const uint16_t* y, int64_t ldy, const float* gate, int64_t rows,
+                         int dim, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Ulysses sequence-parallel exchange layouts (the transposes xfuser / FastVideo's all_to_all_4D do
  * around their all-to-alls: wan/distributed/xdit_context_parallel.py:185-190,

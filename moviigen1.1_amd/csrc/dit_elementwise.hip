@@ -428,5 +428,38 @@ extern "C" int mg_lincomb4_f32(float* out, int64_t n, const float* x0, float c0,
     return mg_check_launch();
 }
 
+// ---------------------------------------------------------------------------------------------
+// x[r][c] += y[r][c] * gate[c]   (x fp32 residual stream, y bf16, gate fp32 or NULL = 1): the gated residual of
+// model.py:301-302,306,308-309 as its own kernel — used when the producer of y is not one of this library's GEMMs
+// (a caller-replaced WanSelfAttention.forward, the operator seam of text2video.py:97-100); the GEMM epilogue
+// MG_EPI_GATE_RESID_F32 is the fused form of the same arithmetic.
+// ---------------------------------------------------------------------------------------------
+__global__ void gate_residual_kernel(float* __restrict__ x, int64_t ldx, const uint16_t* __restrict__ y, int64_t ldy,
+                                     const float* __restrict__ gate, int64_t rows, int vec_per_row) {
+    const int64_t total = rows * vec_per_row;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / vec_per_row;
+        const int c = (int)(i - r * vec_per_row) * 4;
+        const u16x4_t yv = *reinterpret_cast<const u16x4_t*>(y + r * ldy + c);
+        f32x4_t xv = *reinterpret_cast<f32x4_t*>(x + r * ldx + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)   // product rounded, then added (torch: y * e, then x + .) — no fma contraction
+            xv[e] = __fadd_rn(xv[e], __fmul_rn(bf2f(yv[e]), gate ? gate[c + e] : 1.f));
+        *reinterpret_cast<f32x4_t*>(x + r * ldx + c) = xv;
+    }
+}
+
+extern "C" int mg_gate_residual_f32(float* x, int64_t ldx, const uint16_t* y, int64_t ldy, const float* gate, int64_t rows,
+                                    int dim, void* stream) {
+    if (!x || !y) return MG_ERR_ARG;
+    if (rows < 0 || dim <= 0 || (dim & 3) || (ldx & 3) || (ldy & 3)) return MG_ERR_SHAPE;
+    if (rows == 0) return MG_OK;
+    int64_t g = (rows * (dim / 4) + 255) / 256;
+    if (g > 16384) g = 16384;
+    hipLaunchKernelGGL(gate_residual_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, gate, rows,
+                       dim / 4);
+    return mg_check_launch();
+}
+
 extern "C" const char* mg_version(void) { return "moviigen_hip 2 gfx950"; }
 extern "C" int mg_abi_version(void) { return 2; }

@@ -46,6 +46,7 @@ SIGNATURES = {
     'mg_vae_video_out_f32': [c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_int, c_vp],
     'mg_vae_time_interleave_f32': [c_vp, c_int, c_i64, c_int, c_vp, c_vp],
     'mg_video_to_u8': [c_vp, c_int, c_int, c_int, c_f32, c_f32, c_vp, c_vp],
+    'mg_gate_residual_f32': [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int, c_vp],
     'mg_image_to_u8': [c_vp, c_int, c_int, c_f32, c_f32, c_vp, c_vp],
     'mg_sp_pack_qkv_bf16': [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_int, c_vp, c_vp],
     'mg_sp_copy_blocks_bf16': [c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_int, c_i64, c_int, c_vp],

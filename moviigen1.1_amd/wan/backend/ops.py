@@ -239,6 +239,15 @@ def video_to_u8(video, lo=-1.0, hi=1.0):
     return out
 
 
+def gate_residual(x, y, gate=None):
+    """x [rows, dim] fp32 += y [rows, dim] bf16 * gate [dim] fp32 (None = 1)."""
+    _chk(x, torch.float32, 'x'); _chk(y, torch.bfloat16, 'y'); _chk(gate, torch.float32, 'gate')
+    if x.shape != y.shape:
+        raise lib.MoviigenHipError(f'gate_residual shape mismatch x{tuple(x.shape)} y{tuple(y.shape)}')
+    lib.call('mg_gate_residual_f32', _p(x), x.stride(0), _p(y), y.stride(0), _p(gate), x.shape[0], x.shape[1], _st())
+    return x
+
+
 def sp_pack_qkv(q, k, v, P, cols_per_dest, col0, w, send):
     """q, k, v [Lloc, >= P*cols_per_dest] bf16 (column slices ok) -> send [P, Lloc, 3w] (see moviigen_hip.h)."""
     for n, t in (('q', q), ('k', k), ('v', v), ('send', send)):

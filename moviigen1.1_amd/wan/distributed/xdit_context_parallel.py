@@ -1,8 +1,15 @@
 """Sequence-parallel entry points with the reference's names (wan/distributed/
 xdit_context_parallel.py:65-198).  The reference installs `usp_dit_forward` / `usp_attn_forward`
 by method replacement around xfuser; here sequence parallelism is a property of the engine
-(WanModel.sp_size/sp_rank/sp_group) and the collectives are in ulysses.py — these functions
-only configure it, so `types.MethodType(usp_dit_forward, model)` style callers keep working."""
+(WanModel.sp_size/sp_rank/sp_group) and the collectives are in ulysses.py.  `usp_dit_forward` configures it and
+runs the fused forward; `usp_attn_forward` is the stand-alone sequence-parallel attention operator with the
+reference's call shape, so the reference's installation sequence (text2video.py:97-100)
+
+    for block in model.blocks:
+        block.self_attn.forward = types.MethodType(usp_attn_forward, block.self_attn)
+    model.forward = types.MethodType(usp_dit_forward, model)
+
+works unchanged."""
 import torch.distributed as dist
 
 
@@ -29,5 +36,12 @@ def usp_dit_forward(self, x, t, context, seq_len, clip_fea=None, y=None, guidanc
 
 
 def usp_attn_forward(self, x, seq_lens, grid_sizes, freqs, dtype=None):
-    raise RuntimeError('self-attention is fused into WanModel.forward on this engine; enable sequence '
-                       'parallelism with enable_sequence_parallel(model) instead of patching self_attn')
+    """reference xdit_context_parallel.py:155-198, same call shape: `self` is a block's self-attention module,
+    x [B, L/P, C] the rank's token shard; RoPE with the rank's position offset, packed q|k|v all-to-all, attention over
+    all tokens x heads/P, all-to-all back, output projection.  Installing it with
+    `types.MethodType(usp_attn_forward, block.self_attn)` (reference text2video.py:97-100) is honoured: WanModel.forward
+    recognises it and keeps its fused, pipelined implementation of exactly this operator."""
+    sp = None
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        sp = (dist.group.WORLD, dist.get_world_size(), dist.get_rank())
+    return type(self).forward(self, x, seq_lens, grid_sizes, freqs, sp=sp)

@@ -56,20 +56,69 @@ class _Vec(nn.Module):
 
 
 class _Attn(nn.Module):
-    def __init__(self, dim, device):
+    """parameters of WanSelfAttention / WanT2VCrossAttention (reference model.py:102-181).  Inside WanModel.forward
+    attention runs fused in the engine's layer loop; `forward` below is the same operator stand-alone, with the
+    reference's call shape — the operator seam of text2video.py:97-100 (`types.MethodType(fn, block.self_attn)`)."""
+
+    def __init__(self, dim, device, num_heads=None, eps=1e-6):
         super().__init__()
         for n in 'qkvo':
             setattr(self, n, _Lin(dim, dim, torch.bfloat16, device))
         self.norm_q = _Vec(dim, device)
         self.norm_k = _Vec(dim, device)
+        self.dim, self.num_heads, self.eps = dim, num_heads, eps
+
+    def forward(self, x, seq_lens, grid_sizes, freqs=None, sp=None):
+        """WanSelfAttention.forward (model.py:127-156): x [B, L, C] -> [B, L, C] bf16.  `freqs` (the reference's
+        complex table) is accepted and ignored: the rotation angles are rebuilt from grid_sizes (same formula).
+        sp = (group, size, rank): x is the rank's token shard, Ulysses exchange around the attention
+        (usp_attn_forward, xdit_context_parallel.py:155-198)."""
+        d, N = self.dim, self.num_heads
+        hd = d // N
+        scale = 1.0 / math.sqrt(hd)
+        bf = torch.bfloat16
+        outs = []
+        for b in range(x.shape[0]):
+            h = x[b].to(bf).contiguous()
+            L, dev = h.shape[0], h.device
+            grid = tuple(int(v) for v in grid_sizes[b].tolist())
+            rope = rope_cos_sin(hd, grid).to(dev)
+            q, k, v = (torch.empty(L, d, dtype=bf, device=dev) for _ in range(3))
+            for lin, dst in ((self.q, q), (self.k, k), (self.v, v)):
+                ops.gemm(h, lin.weight, lin.bias, ops.BIAS_BF16, dst)
+            P, rank = (sp[1], sp[2]) if sp else (1, 0)
+            qn, kn = torch.empty_like(q), torch.empty_like(k)
+            ops.rmsnorm_rope(q, self.norm_q.weight, self.eps, hd, qn, rope, grid, rank * L)
+            ops.rmsnorm_rope(k, self.norm_k.weight, self.eps, hd, kn, rope, grid, rank * L)
+            a = torch.empty(L, d, dtype=bf, device=dev)
+
+            def attend(qg, kg, vg, ag, heads, klen):
+                if hd == 128:
+                    n_pk = ops.packed_kv_numel(klen, heads)
+                    kp, vp = torch.empty(n_pk, dtype=bf, device=dev), torch.empty(n_pk, dtype=bf, device=dev)
+                    ops.pack_kv(kg[:klen], vg[:klen], heads, kp, vp)
+                    ops.attention_hd128(qg, kp, vp, ag, klen, heads, scale)
+                else:
+                    ops.attention_generic(qg, kg, vg, ag, klen, heads, hd, scale)
+            if P > 1:
+                from ..distributed.ulysses import HeadExchange
+                ex = HeadExchange(sp[0], P, N, hd, L, dev)
+                ex.run(qn, kn, v, a, lambda qg, kg, vg, ag, n: attend(qg, kg, vg, ag, n, kg.shape[0]))
+            else:
+                klen = min(L, int(seq_lens[b])) if seq_lens is not None else L
+                attend(qn, kn, v, a, N, klen)
+            o = torch.empty(L, d, dtype=bf, device=dev)
+            ops.gemm(a, self.o.weight, self.o.bias, ops.BIAS_BF16, o)
+            outs.append(o)
+        return torch.stack(outs)
 
 
 class _Block(nn.Module):
-    def __init__(self, dim, ffn_dim, device):
+    def __init__(self, dim, ffn_dim, device, num_heads=None, eps=1e-6):
         super().__init__()
-        self.self_attn = _Attn(dim, device)
+        self.self_attn = _Attn(dim, device, num_heads, eps)
         self.norm3 = _Vec(dim, device, bias=True)
-        self.cross_attn = _Attn(dim, device)
+        self.cross_attn = _Attn(dim, device, num_heads, eps)
         self.ffn = nn.ModuleDict({'0': _Lin(ffn_dim, dim, torch.bfloat16, device),
                                   '2': _Lin(dim, ffn_dim, torch.bfloat16, device)})
         self.modulation = nn.Parameter(torch.empty(1, 6, dim, dtype=torch.float32, device=device),
@@ -90,6 +139,18 @@ class _PatchEmbed(nn.Module):
         self.weight = nn.Parameter(torch.empty(dim, in_dim, *patch, dtype=torch.bfloat16, device=device),
                                    requires_grad=False)
         self.bias = nn.Parameter(torch.empty(dim, dtype=torch.float32, device=device), requires_grad=False)
+
+
+def _replaced_forward(attn):
+    """the instance-level `forward` a caller installed on a self-attention module (types.MethodType), unless it is
+    one of this engine's own entry points (usp_attn_forward only re-states what the fused loop does anyway)."""
+    fn = attn.__dict__.get('forward')
+    if fn is None:
+        return None
+    from ..distributed.xdit_context_parallel import usp_attn_forward
+    if getattr(fn, '__func__', fn) in (usp_attn_forward, _Attn.forward):
+        return None
+    return fn
 
 
 def rope_cos_sin(head_dim, grid, theta=10000.0):
@@ -134,11 +195,15 @@ class WanModel(nn.Module):
         self.time_embedding = nn.ModuleDict({'0': _Lin(dim, freq_dim, torch.float32, dv),
                                              '2': _Lin(dim, dim, torch.float32, dv)})
         self.time_projection = nn.ModuleDict({'1': _Lin(6 * dim, dim, torch.float32, dv)})
-        self.blocks = nn.ModuleList([_Block(dim, ffn_dim, dv) for _ in range(num_layers)])
+        self.blocks = nn.ModuleList([_Block(dim, ffn_dim, dv, num_heads, eps) for _ in range(num_layers)])
         self.head = _Head(dim, math.prod(self.patch_size) * out_dim, dv)
         # sequence-parallel placement, installed by wan.distributed (Ulysses); 1 = single GPU
         self.sp_size, self.sp_rank, self.sp_group = 1, 0, None
         self.sp_force = False   # run the Ulysses collectives even on a 1-rank group (RCCL smoke test)
+        # training-side SP forward (scripts/train/model/model_seq.py): the sequence is zero-padded to seq_len before it
+        # is chunked over the ranks and padded keys are masked (k_lens); cross-attention is head-sharded
+        self.sp_mask_padded_keys = False
+        self.cross_attn_head_sharded = False
         self.ring = False       # sequence parallelism by ring attention instead of Ulysses (wan/distributed/ring.py)
         # hybrid layout (wan/distributed/ring.py: enable_hybrid_sp): Ulysses inside groups of `uly_size` consecutive
         # ranks, ring attention across the `ring_size` groups; None = derive from sp_size / ring
@@ -147,6 +212,20 @@ class WanModel(nn.Module):
         self._ws = {}
         self._rope = {}
         self._ctx_cache = {}
+
+    @property
+    def freqs(self):
+        """the reference's complex RoPE table [1024, head_dim/2] (model.py:473-478), built on demand for callers of
+        the operator seam; the engine's kernels use rope_cos_sin() instead."""
+        if getattr(self, '_freqs', None) is None:
+            d = self.dim // self.num_heads
+
+            def params(dim):
+                ang = torch.outer(torch.arange(1024, dtype=torch.float64),
+                                  1.0 / torch.pow(10000.0, torch.arange(0, dim, 2, dtype=torch.float64) / dim))
+                return torch.polar(torch.ones_like(ang), ang)
+            self._freqs = torch.cat([params(d - 4 * (d // 6)), params(2 * (d // 6)), params(2 * (d // 6))], dim=1)
+        return self._freqs
 
     # ------------------------------------------------------------------------------------------
     # checkpoint layout (reference text2video.py:87, SURVEY.md §5)
@@ -385,10 +464,11 @@ class WanModel(nn.Module):
                 from ..distributed.ring import ring_attention
                 ring_attention(qg, kg, vg, ag, ws, rg, R, rr, heads, scale)
             elif hd == 128:
-                ops.pack_kv(kg, vg, heads, ws['kp'], ws['vp'])
-                ops.attention_hd128(qg, ws['kp'], ws['vp'], ag, kg.shape[0], heads, scale)
+                kv = min(kg.shape[0], self._kv_valid)       # keys past the video's tokens are padding (k_lens)
+                ops.pack_kv(kg[:kv], vg[:kv], heads, ws['kp'], ws['vp'])
+                ops.attention_hd128(qg, ws['kp'], ws['vp'], ag, kv, heads, scale)
             else:
-                ops.attention_generic(qg, kg, vg, ag, kg.shape[0], heads, hd, scale)
+                ops.attention_generic(qg, kg, vg, ag, min(kg.shape[0], self._kv_valid), heads, hd, scale)
 
         if U > 1 or self.sp_force:
             # Ulysses: packed q|k|v exchange per head group on the comm stream, pipelined against the attention
@@ -396,6 +476,26 @@ class WanModel(nn.Module):
             ws['xchg'].run(q, k, v, a, attend)
         else:                                   # pure ring: every rank keeps all heads
             attend(q, k, v, a, N)
+
+    def _cross_attention_head_sharded(self, ws, kc, vc):
+        """model_seq.py:271-294: q through the seq->head all-to-all, K/V narrowed to this rank's heads (shrink_head),
+        attention over ALL tokens x local heads, head->seq all-to-all back.  Same values as the token-local form."""
+        from ..distributed import ulysses
+        U = self._sp_layout()[0]
+        ug = self.uly_group if self.uly_group is not None else self.sp_group
+        ur = self.sp_rank % U
+        N, hd = self.num_heads, self.dim // self.num_heads
+        nl, L = N // U, ws['k'].shape[0]
+        qg = torch.empty(L * U, nl * hd, dtype=torch.bfloat16, device=ws['k'].device)
+        ulysses.seq_to_head(ws['k'], qg, ug, U, N, hd)
+        ag = torch.empty_like(qg)
+        if hd == 128:      # packed K/V are head-major: this rank's heads are one contiguous range of tiles
+            per_head = kc.numel() // N
+            ks, vs = kc[ur * nl * per_head:(ur + 1) * nl * per_head], vc[ur * nl * per_head:(ur + 1) * nl * per_head]
+        else:
+            ks, vs = kc[:, ur * nl * hd:(ur + 1) * nl * hd], vc[:, ur * nl * hd:(ur + 1) * nl * hd]
+        self._attention(qg, ks, vs, ag, self.text_len, nl)
+        ulysses.head_to_seq(ag, ws['a'], ug, U, N, hd)
 
     @torch.no_grad()
     def _forward_one(self, lat, t, ctx, seq_len):
@@ -409,13 +509,20 @@ class WanModel(nn.Module):
         Lfull = grid[0] * grid[1] * grid[2]
         assert Lfull <= seq_len, 'seq_lens.max() <= seq_len (reference model.py:534)'
         P = self.sp_size
-        if P > 1:
+        Ltot = Lfull
+        if P > 1 and self.sp_mask_padded_keys:
+            # model_seq.py:704-706,757: pad to seq_len, chunk; padded keys masked through k_lens (:247-252)
+            assert seq_len % P == 0 and self.num_heads % self._sp_layout()[0] == 0 and self._sp_layout()[1] == 1, \
+                'training-side sequence parallel needs seq_len % sp == 0, heads % sp == 0 (Ulysses only)'
+            Ltot = seq_len
+        elif P > 1:
             # reference SP path does not mask padded keys (xdit_context_parallel.py:178-193): it is
             # only correct without padding, which is what every supported size gives
             assert seq_len == Lfull and Lfull % P == 0 and self.num_heads % self._sp_layout()[0] == 0, \
                 'sequence parallel needs L % sp == 0, heads % sp == 0 and no padding'
-        L = Lfull // P
+        L = Ltot // P
         pos0 = self.sp_rank * L
+        n_valid = min(max(Lfull - pos0, 0), L)          # video tokens among this rank's rows (all of them unless padded)
         self._kv_valid = Lfull
         d, eps = self.dim, self.eps
         ws = self._workspace(L, dev)
@@ -427,8 +534,11 @@ class WanModel(nn.Module):
         else:
             full = torch.empty(Lfull, ws['tok'].shape[1], dtype=torch.bfloat16, device=dev)
             ops.patchify(lat, ph, pw, full)
-            ws['tok'].copy_(full[pos0:pos0 + L])  # torch.chunk(x, P, dim=1)[rank]
-        ops.gemm(ws['tok'], pk['patch_w'], self.patch_embedding.bias, ops.BIAS_F32, x)
+            ws['tok'][:n_valid].copy_(full[pos0:pos0 + n_valid])  # torch.chunk(x, P, dim=1)[rank]
+        if n_valid:
+            ops.gemm(ws['tok'][:n_valid], pk['patch_w'], self.patch_embedding.bias, ops.BIAS_F32, x[:n_valid])
+        if n_valid < L:
+            x[n_valid:].zero_()                          # rows padded AFTER the patch embedding (no bias), :704-706
 
         # time embedding (model.py:541-545), fp32
         tt = t.reshape(1).to(dev)
@@ -451,9 +561,16 @@ class WanModel(nn.Module):
             m = mod[6 * i:6 * i + 6]
             # self attention
             ops.ln_modulate(x, m[1], m[0], True, eps, ws['h'], round_norm_bf16=(i == 0))
-            ops.gemm(ws['h'], lw['wqkv'], lw['bqkv'], ops.BIAS_BF16, ws['qkv'])
-            self._self_attention(ws, blk, grid, rope, L, pos0)
-            ops.gemm(ws['a'], lw['self_attn.o'], blk.self_attn.o.bias, ops.GATE_RESID_F32, x, gate=m[2])
+            custom = _replaced_forward(blk.self_attn)
+            if custom is None:
+                ops.gemm(ws['h'], lw['wqkv'], lw['bqkv'], ops.BIAS_BF16, ws['qkv'])
+                self._self_attention(ws, blk, grid, rope, L, pos0)
+                ops.gemm(ws['a'], lw['self_attn.o'], blk.self_attn.o.bias, ops.GATE_RESID_F32, x, gate=m[2])
+            else:
+                # operator seam (2) of the reference (text2video.py:97-100): the caller replaced
+                # block.self_attn.forward — call it with the reference's arguments and keep the fused rest
+                y = custom(ws['h'][None], torch.tensor([Lfull]), torch.tensor([list(grid)]), self.freqs)
+                ops.gate_residual(x, y[0].to(torch.bfloat16).contiguous(), m[2])
             # cross attention (text keys/values cached per prompt)
             ca = blk.cross_attn
             if ctx_layers[i] is None:          # first forward with this prompt
@@ -462,7 +579,10 @@ class WanModel(nn.Module):
             ops.ln_modulate(x, blk.norm3.weight, blk.norm3.bias, False, eps, ws['h'])
             ops.gemm(ws['h'], lw['cross_attn.q'], ca.q.bias, ops.BIAS_BF16, ws['q'])
             ops.rmsnorm_rope(ws['q'], ca.norm_q.weight, eps, d // self.num_heads, ws['k'])
-            self._attention(ws['k'], kc, vc, ws['a'], self.text_len, self.num_heads)
+            if self.cross_attn_head_sharded and P > 1:
+                self._cross_attention_head_sharded(ws, kc, vc)
+            else:
+                self._attention(ws['k'], kc, vc, ws['a'], self.text_len, self.num_heads)
             ops.gemm(ws['a'], lw['cross_attn.o'], ca.o.bias, ops.GATE_RESID_F32, x, gate=None)
             # ffn
             ops.ln_modulate(x, m[4], m[3], True, eps, ws['h'])

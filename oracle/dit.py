@@ -16,6 +16,7 @@ algorithm of the reference files (paths relative to the reference tree):
   wan/modules/model.py:316-343  Head                           -> head()
   wan/modules/model.py:486-609  WanModel.forward / unpatchify  -> dit_forward(), unpatchify()
   wan/distributed/xdit_context_parallel.py:23-62,65-152,155-198 (Ulysses SP)  -> dit_forward_sp_sim()
+  scripts/train/model/model_seq.py:37-76,197-294,621-790 (training-side SP forward) -> dit_forward_train_sp_sim()
 
 Two numeric modes:
   emulate_bf16=False : everything fp32 (RoPE fp64) — what the reference itself computes on CPU,
@@ -283,4 +284,78 @@ def dit_forward_sp_sim(P, cfg, lat, t, ctx, seq_len, sp, emulate_bf16=False):
               for r in range(sp)]
     ys = [head(P, xs[r], e[0], cfg['eps']) for r in range(sp)]
     y = torch.cat(ys, dim=0)  # all_gather(dim=1) of the reference
+    return unpatchify(y, grid, cfg['patch_size'], cfg['out_dim']).to(torch.float32)
+
+
+# ------------------------------------------------------------------------------------------------
+# training-side sequence-parallel forward (scripts/train/model/model_seq.py), simulated in ONE process
+# ------------------------------------------------------------------------------------------------
+def dit_forward_train_sp_sim(P, cfg, lat, t, batch_context, seq_len, sp, emulate_bf16=False):
+    """scripts/train/model/model_seq.py:621-790 with its collectives replaced by list shuffles:
+
+      * the token sequence is zero-padded to seq_len AFTER the patch embedding (:704-706) and chunked over the sp
+        ranks (:757) — a rank may hold padded rows;
+      * rope_apply_dist (:37-76): the rank's slice of the position table, padded with identity rotations;
+      * self-attention (:197-256): all_to_all_4D to [all tokens, heads/sp], flash_attention with k_lens = the video's
+        token count (padded keys masked), all_to_all_4D back;
+      * cross-attention (:271-294): q goes through the same all-to-all, K/V keep this rank's heads (shrink_head),
+        attention over all tokens x local heads, all-to-all back;
+      * all_gather of x along tokens (:780), head and unpatchify on the gathered sequence.
+
+    batch_context [text_len, text_dim]: the prompt embedding already padded (the `batch_context` argument, :748)."""
+    bf = emulate_bf16
+    N, eps = cfg['num_heads'], cfg['eps']
+    x, grid = patch_embed(P, lat.to(torch.float32), cfg['patch_size'], bf)
+    L, dim = x.shape
+    hd = dim // N
+    assert L <= seq_len and seq_len % sp == 0 and N % sp == 0
+    x = torch.cat([x, torch.zeros(seq_len - L, dim)])
+    e, e0 = time_embed(P, t.reshape(1), cfg['freq_dim'])
+    assert batch_context.shape[0] == cfg['text_len']
+    c = text_embed(P, batch_context, cfg['text_len'], bf)
+    Lc = c.shape[0]
+    tables = rope_table(hd)
+    lr = seq_len // sp
+    nl = N // sp
+    xs = [x[r * lr:(r + 1) * lr] for r in range(sp)]
+    for i in range(cfg['num_layers']):
+        pre = f'blocks.{i}.'
+        em = (P[pre + 'modulation'][0] + e0[0]).to(torch.float32)
+        sa, ca = pre + 'self_attn.', pre + 'cross_attn.'
+        qs, ks, vs = [], [], []
+        for r in range(sp):
+            y = layernorm(xs[r], eps)
+            if i == 0 and bf:
+                y = _bf(y, True)
+            h = y * (1 + em[1]) + em[0]
+            q = rmsnorm(linear(h, P[sa + 'q.weight'], P[sa + 'q.bias'], bf), P[sa + 'norm_q.weight'], eps, bf)
+            k = rmsnorm(linear(h, P[sa + 'k.weight'], P[sa + 'k.bias'], bf), P[sa + 'norm_k.weight'], eps, bf)
+            v = linear(h, P[sa + 'v.weight'], P[sa + 'v.bias'], bf)
+            qs.append(rope(q.view(lr, N, hd), grid, tables, r * lr))
+            ks.append(rope(k.view(lr, N, hd), grid, tables, r * lr))
+            vs.append(v.view(lr, N, hd))
+        qh, kh, vh = all_to_all_seq_to_head(qs), all_to_all_seq_to_head(ks), all_to_all_seq_to_head(vs)
+        os_ = all_to_all_head_to_seq([attention(qh[r], kh[r], vh[r], L, bf) for r in range(sp)])
+        for r in range(sp):
+            y = linear(os_[r].reshape(lr, dim), P[sa + 'o.weight'], P[sa + 'o.bias'], bf)
+            xs[r] = xs[r].to(torch.float32) + y * em[2]
+        # cross-attention, head-sharded
+        kc = rmsnorm(linear(c, P[ca + 'k.weight'], P[ca + 'k.bias'], bf), P[ca + 'norm_k.weight'], eps, bf).view(Lc, N, hd)
+        vc = linear(c, P[ca + 'v.weight'], P[ca + 'v.bias'], bf).view(Lc, N, hd)
+        qs = []
+        for r in range(sp):
+            h = layernorm(xs[r], eps, P[pre + 'norm3.weight'], P[pre + 'norm3.bias'])
+            qs.append(rmsnorm(linear(h, P[ca + 'q.weight'], P[ca + 'q.bias'], bf), P[ca + 'norm_q.weight'], eps,
+                              bf).view(lr, N, hd))
+        qh = all_to_all_seq_to_head(qs)
+        os_ = all_to_all_head_to_seq([attention(qh[r], kc[:, r * nl:(r + 1) * nl], vc[:, r * nl:(r + 1) * nl], Lc, bf)
+                                      for r in range(sp)])
+        for r in range(sp):
+            xs[r] = xs[r] + linear(os_[r].reshape(lr, dim), P[ca + 'o.weight'], P[ca + 'o.bias'], bf)
+            h = layernorm(xs[r], eps) * (1 + em[4]) + em[3]
+            u = linear(h, P[pre + 'ffn.0.weight'], P[pre + 'ffn.0.bias'], bf)
+            u = _bf(F.gelu(u, approximate='tanh'), bf)
+            xs[r] = xs[r] + linear(u, P[pre + 'ffn.2.weight'], P[pre + 'ffn.2.bias'], bf) * em[5]
+    xg = torch.cat(xs, dim=0)                       # all_gather(x, dim=1)
+    y = head(P, xg, e[0], eps)
     return unpatchify(y, grid, cfg['patch_size'], cfg['out_dim']).to(torch.float32)

@@ -294,6 +294,70 @@ def test_dit_hd128_padded_seq_len(dev):
     assert rel_l2(out, out48) < 1e-6          # padding never changes the video tokens
 
 
+def test_operator_seam_self_attention(dev):
+    """operator seam (2) of the reference (text2video.py:97-100): block.self_attn is callable with
+    WanSelfAttention.forward's arguments; a caller-installed replacement (types.MethodType) is really called by
+    WanModel.forward; the reference's own usp_attn_forward / usp_dit_forward installation keeps the fused path."""
+    import types
+    import wan
+    from oracle import dit
+    from wan.distributed.xdit_context_parallel import usp_attn_forward, usp_dit_forward
+    cfg = W.SMALL_DIT_HD128
+    P = W.make_dit_params(cfg, 0)
+    m = wan.modules.WanModel(**cfg)
+    m.load_state_dict(P)
+    m.to(dev)
+    # (a) the stand-alone operator vs the oracle's restatement of model.py:127-156 (bf16 rounding model)
+    L, grid, N, hd = 48, (2, 4, 6), cfg['num_heads'], cfg['dim'] // cfg['num_heads']
+    x = W.randn((1, 60, cfg['dim']), 91)                      # 48 video tokens + 12 padded rows, k_lens masks them
+    sa = 'blocks.1.self_attn.'
+    got = m.blocks[1].self_attn(x.to(dev), torch.tensor([L]), torch.tensor([list(grid)]), m.freqs)
+    assert got.dtype == torch.bfloat16 and tuple(got.shape) == (1, 60, cfg['dim'])
+    h = x[0]
+    tabs = dit.rope_table(hd)
+    q = dit.rmsnorm(dit.linear(h, P[sa + 'q.weight'], P[sa + 'q.bias'], True), P[sa + 'norm_q.weight'], 1e-6, True)
+    k = dit.rmsnorm(dit.linear(h, P[sa + 'k.weight'], P[sa + 'k.bias'], True), P[sa + 'norm_k.weight'], 1e-6, True)
+    v = dit.linear(h, P[sa + 'v.weight'], P[sa + 'v.bias'], True)
+    a = dit.attention(dit.rope(q.view(60, N, hd), grid, tabs), dit.rope(k.view(60, N, hd), grid, tabs),
+                      v.view(60, N, hd), L, True)
+    ref = dit.linear(a.reshape(60, -1), P[sa + 'o.weight'], P[sa + 'o.bias'], True)
+    assert scale_err(got[0, :L], ref[:L]) < 2e-2
+    # (b) a caller-installed forward is honoured by the fused loop
+    lat, ctx, t = W.randn((16, 2, 8, 12), 20).to(dev), W.randn((33, cfg['text_dim']), 30).to(dev), torch.tensor([999], device=dev)
+    base = m([lat], t=t, context=[ctx], seq_len=48)[0].clone()
+    calls = []
+
+    def my_attn(self, x, seq_lens, grid_sizes, freqs):
+        calls.append((tuple(x.shape), int(seq_lens[0]), tuple(grid_sizes[0].tolist()), tuple(freqs.shape)))
+        return type(self).forward(self, x, seq_lens, grid_sizes, freqs)
+    for blk in m.blocks:
+        blk.self_attn.forward = types.MethodType(my_attn, blk.self_attn)
+    out = m([lat], t=t, context=[ctx], seq_len=48)[0]
+    assert len(calls) == cfg['num_layers'] and calls[0] == ((1, 48, cfg['dim']), 48, (2, 4, 6), (1024, hd // 2))
+    assert rel_l2(out, base) < 1e-6
+    # (c) the reference's installation sequence: fused path, same result, replacement NOT treated as foreign
+    calls.clear()
+    for blk in m.blocks:
+        blk.self_attn.forward = types.MethodType(usp_attn_forward, blk.self_attn)
+    m.forward = types.MethodType(usp_dit_forward, m)
+    out = m([lat], t=t, context=[ctx], seq_len=48)[0]
+    assert torch.equal(out, base) and not calls
+    one = m.blocks[0].self_attn.forward(x.to(dev), torch.tensor([L]), torch.tensor([list(grid)]), m.freqs)
+    assert tuple(one.shape) == (1, 60, cfg['dim'])
+
+
+def test_gate_residual_kernel(dev):
+    from wan.backend import ops
+    x = W.randn((37, 256), 5).to(dev)
+    y = W.randn((37, 256), 6).to(dev).bfloat16()
+    g = W.randn((256,), 7).to(dev)
+    ref = x + y.float() * g
+    ops.gate_residual(x, y, g)
+    assert torch.equal(x, ref)
+    ops.gate_residual(x, y, None)
+    assert torch.equal(x, ref + y.float())
+
+
 def test_dit_context_cache_and_determinism(dev):
     import wan
     cfg = W.SMALL_DIT_HD128
@@ -704,6 +768,21 @@ def test_rccl_multi_gpu(layout):
         pytest.skip('needs >= 2 GPUs (RCCL refuses two ranks on one device)')
     world = 8 if n >= 8 else 4 if n >= 4 else 2
     _run_hybrid(world, 'nccl', layout, 29630 + world)
+
+
+def test_train_side_sp_forward_one_gpu():
+    """SURVEY 8(f) rank 4, second half: the training-side sequence-parallel DiT forward (reference
+    scripts/train/model/model_seq.py) on the engine, 2 gloo ranks on cuda:0, vs the reference-generated golden g8
+    (with and without padded rows) and bit-identical to the single-rank forward."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
+                        '--master-addr', '127.0.0.1', '--master-port', '29655',
+                        os.path.join(root, 'tests', 'dist_train_seq_worker.py')], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert 'TRAIN_SEQ_OK rank0/2' in r.stdout and 'TRAIN_SEQ_OK rank1/2' in r.stdout
 
 
 def test_launcher_end_to_end(dev, tmp_path):

@@ -199,3 +199,33 @@ def test_t5_state_dict_names():
         m(torch.zeros(1, 4, dtype=torch.long))          # no CPU path
     with pytest.raises(NotImplementedError):
         umt5_xxl(encoder_only=False)
+
+
+@pytest.mark.parametrize('tag', ['nopad', 'pad'])
+def test_train_side_sp_forward(golden, tag):
+    """g8: the reference's training-side sequence-parallel DiT (scripts/train/model/model_seq.py) run as 2 lock-step
+    ranks (tests/golden/make_golden_seq.py) vs the oracle's list-shuffle simulation of the same forward; 'pad' has
+    seq_len 56 > 48 video tokens (rank 1 holds padded rows, padded keys are masked)."""
+    g = golden('g8_train_seq')
+    cfg = W.SMALL_DIT_HD128
+    P = W.make_dit_params(cfg, 0)
+    args = (P, cfg, T(g['lat']), T(g['t']), T(g['batch_context'])[0], int(g[f'seq_len_{tag}']), 2)
+    out32 = dit.dit_forward_train_sp_sim(*args, emulate_bf16=False)
+    assert maxerr(out32, g[f'sp2_fp32_{tag}']) < 1e-5
+    assert maxerr(out32, g[f'single_fp32_{tag}']) < 1e-5          # the reference's own SP == its single-rank forward
+    outbf = dit.dit_forward_train_sp_sim(*args, emulate_bf16=True)
+    assert rel_l2(outbf, g[f'sp2_bf16_{tag}']) < 1e-2
+    assert rel_l2(g[f'sp2_bf16_{tag}'], g[f'sp2_fp32_{tag}']) < 2e-2
+    # one-rank simulation == the plain inference forward of the oracle (same algorithm, different plumbing)
+    plain = dit.dit_forward(P, cfg, T(g['lat']), T(g['t']), T(g['batch_context'])[0, :33], int(g[f'seq_len_{tag}']))
+    assert maxerr(plain, out32) < 1e-5
+
+
+def test_rope_apply_dist(golden):
+    """model_seq.py:37-76: the rank's slice of the position table, identity rotation on the padded rows."""
+    g = golden('g8_train_seq')
+    grid = tuple(int(v) for v in g['rope_dist_grid'][0])
+    tabs = dit.rope_table(128)
+    x = T(g['rope_dist_x'])[0]
+    for r in range(2):
+        assert maxerr(dit.rope(x, grid, tabs, pos0=r * x.shape[0]), g[f'rope_dist_rank{r}'][0]) < 1e-6
