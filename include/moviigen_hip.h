@@ -95,11 +95,12 @@ int mg_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw,
                  const float* bias, int64_t M, int N, int K, int epilogue, void* out,
                  int64_t ldo, const float* gate, void* stream);
 
-/* Tile schedule of mg_gemm_bf16 (same results bit for bit):
+/* Tile schedule of mg_gemm_bf16 (same results bit for bit) — a process-global MEASUREMENT / TEST switch, not part of
+ * the drop-in contract and not thread-safe; the default (5) already selects by shape:
  * 5 (default) = 256x256x64 tile, 4 waves = ONE per SIMD (128x128 each, accumulators in AGPRs), 2 LDS
  *     stages, LDS-DMA pieces and fragment reads spread between the MFMAs (M > 256 and N > 128, else 2);
- * 3 = 256x256x64 tile, 8 waves (128x64 each); 2 = 256x128x64 tile, 8 waves, 3-stage LDS ring with
- *     counted vmcnt (M > 128, else 1); 1 = 128x128x64 tile, 4 waves, 2 stages. */
+ * 2 = 256x128x64 tile, 8 waves, 3-stage LDS ring with counted vmcnt (M > 128, else 1);
+ * 1 = 128x128x64 tile, 4 waves, 2 stages. */
 void mg_gemm_set_variant(int variant);
 
 /* softmax(q k^T * scale) v, non-causal, keys >= Lk masked; bf16 in/out, fp32 accumulate,
@@ -293,6 +294,17 @@ int mg_image_to_u8(const float* image, int H, int W, float lo, float hi, uint8_t
 /* time_conv channel halves -> interleaved frames (vae.py:133-137):
  * x [T][H][W][2C] -> out [2T][H][W][C], frame 2t from channels [0,C), 2t+1 from [C,2C). */
 int mg_vae_time_interleave_f32(const float* x, int T, int64_t HW, int C, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Debug / profiling hooks.  NOT part of the drop-in contract (no reference counterpart): used by
+ * csrc/tools/selftest.cpp and tools/ to take s_memtime breakdowns of the hot loops and to force kernel
+ * schedules for A/B measurements.  All are process-global switches; passing NULL / 0 restores the default.
+ * ---------------------------------------------------------------------------------------- */
+void mg_attn_debug_profile(unsigned long long* dev_buf);   /* lock-step attention: 8 waves x {S^T, softmax, P.V, fence, tiles} cycles */
+void mg_attn_w64_profile(unsigned long long* dev_buf);     /* w64 attention: 4 waves x {fence, step A, step B, iterations} */
+void mg_attn_w64_debug(int flags);                         /* bit 0: keep the pipelined result of flagged blocks (no exact pass) */
+void mg_gemm_debug_profile(unsigned long long* dev_buf);   /* GEMM variants 1/2: 8 waves x {wait+barrier, stage issue, MFMA, k-tiles} */
+void mg_gemm5_debug_profile(unsigned long long* dev_buf);  /* GEMM variant 5: 4 waves x the same four counters */
 
 #ifdef __cplusplus
 }

@@ -438,13 +438,14 @@ __global__ void gate_residual_kernel(float* __restrict__ x, int64_t ldx, const u
                                      const float* __restrict__ gate, int64_t rows, int vec_per_row) {
     const int64_t total = rows * vec_per_row;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+#pragma clang fp contract(off)
         const int64_t r = i / vec_per_row;
         const int c = (int)(i - r * vec_per_row) * 4;
         const u16x4_t yv = *reinterpret_cast<const u16x4_t*>(y + r * ldy + c);
         f32x4_t xv = *reinterpret_cast<f32x4_t*>(x + r * ldx + c);
 #pragma unroll
         for (int e = 0; e < 4; ++e)   // product rounded, then added (torch: y * e, then x + .) — no fma contraction
-            xv[e] = __fadd_rn(xv[e], __fmul_rn(bf2f(yv[e]), gate ? gate[c + e] : 1.f));
+            xv[e] = xv[e] + bf2f(yv[e]) * (gate ? gate[c + e] : 1.f);
         *reinterpret_cast<f32x4_t*>(x + r * ldx + c) = xv;
     }
 }
@@ -461,5 +462,5 @@ extern "C" int mg_gate_residual_f32(float* x, int64_t ldx, const uint16_t* y, in
     return mg_check_launch();
 }
 
-extern "C" const char* mg_version(void) { return "moviigen_hip 2 gfx950"; }
-extern "C" int mg_abi_version(void) { return 2; }
+extern "C" const char* mg_version(void) { return "moviigen_hip 3 gfx950"; }
+extern "C" int mg_abi_version(void) { return 3; }   // 3 = 2 + the exchange layouts, mg_gate_residual_f32, mg_image_to_u8 (additions only)

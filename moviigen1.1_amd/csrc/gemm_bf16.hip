@@ -136,12 +136,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(
 
 int mg_gemm_v5_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_t ldw, const float* bias, int64_t M,
                       int N, int K, int epilogue, void* out, int64_t ldo, const float* gate, hipStream_t st);
-int mg_gemm_v3_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_t ldw, const float* bias, int64_t M,
-                      int N, int K, int epilogue, void* out, int64_t ldo, const float* gate, hipStream_t st);
 int mg_gemm_v2_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_t ldw, const float* bias, int64_t M,
                       int N, int K, int epilogue, void* out, int64_t ldo, const float* gate, hipStream_t st);
 
-static int g_gemm_variant = 5;  // 1 = 128x128 tile, 2 LDS stages (this file); 2 = 256x128, 3 stages (gemm_bf16_v2.hip); 3 = 256x256, 8 waves, 2 stages (gemm_bf16_v3.hip); 5 = 256x256, 4 waves = one per SIMD (gemm_bf16_v5.hip)
+// tile schedule: 1 = 128x128 tile, 2 LDS stages (this file); 2 = 256x128, 3 stages (gemm_bf16_v2.hip); 5 = 256x256, 4 waves =
+// one per SIMD (gemm_bf16_v5.hip).  (3, the 8-wave 256x256 tile, was an A/B partner only: experiments/gemm_bf16_v3_8waves.hip.)
+// Process-global and NOT thread-safe on purpose: a measurement / test switch (tools/, tests/conftest.py resets it after
+// every test), never touched by the product path — mg_gemm_bf16 itself picks by shape.
+static int g_gemm_variant = 5;
 extern "C" void mg_gemm_set_variant(int v) { g_gemm_variant = v; }
 
 extern "C" int mg_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_t ldw,
@@ -156,9 +158,7 @@ extern "C" int mg_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* Wt, 
     if (M == 0) return MG_OK;
     if (g_gemm_variant == 5 && M > 256 && N > 128)
         return mg_gemm_v5_launch(A, lda, Wt, ldw, bias, M, N, K, epilogue, out, ldo, gate, (hipStream_t)stream);
-    if (g_gemm_variant == 3 && M > 256 && N > 128)
-        return mg_gemm_v3_launch(A, lda, Wt, ldw, bias, M, N, K, epilogue, out, ldo, gate, (hipStream_t)stream);
-    if (g_gemm_variant >= 2 && M > 128)  // tiny M: the 128-row tile wastes less (variants 3 and 5 fall through to here for narrow shapes)
+    if (g_gemm_variant >= 2 && M > 128)  // tiny M: the 128-row tile wastes less (variant 5 falls through to here for narrow shapes)
         return mg_gemm_v2_launch(A, lda, Wt, ldw, bias, M, N, K, epilogue, out, ldo, gate, (hipStream_t)stream);
     const int64_t tiles_m64 = (M + BM - 1) / BM;
     const int tiles_n = (N + BN - 1) / BN;

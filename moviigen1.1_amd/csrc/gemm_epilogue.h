@@ -88,6 +88,8 @@ MG_DEV void mg_gemm_epilogue(const f32x16_t (&acc)[NI][NJ], int64_t m_wave, int 
                 float* o = (float*)out + m * ldo + n;
                 float4 r = make_float4(v[0], v[1], v[2], v[3]);
                 if (EPI == MG_EPI_GATE_RESID_F32) {
+                    // torch evaluates `x + y * e` as a rounded product and a rounded sum (two kernels): no fma here
+#pragma clang fp contract(off)
                     r.x = x4[c].x + v[0] * g4[c].x;
                     r.y = x4[c].y + v[1] * g4[c].y;
                     r.z = x4[c].z + v[2] * g4[c].z;

@@ -14,7 +14,6 @@ extern "C" void mg_attn_debug_profile(unsigned long long* dev_buf);
 extern "C" void mg_gemm_debug_profile(unsigned long long* dev_buf);
 extern "C" void mg_attn_w64_debug(int flags);
 extern "C" void mg_attn_w64_profile(unsigned long long* dev_buf);
-extern "C" void mg_gemm3_debug_profile(unsigned long long* dev_buf);
 extern "C" void mg_gemm5_debug_profile(unsigned long long* dev_buf);
 
 #define CK(x)                                                                      \
@@ -534,7 +533,7 @@ int main(int argc, char** argv) {
         CK(hipMemset(buf, 0, 32 * 8));
         const int gv = argc > 2 ? atoi(argv[2]) : 2;
         mg_gemm_set_variant(gv);
-        if (gv == 5) mg_gemm5_debug_profile(buf); else if (gv == 3) mg_gemm3_debug_profile(buf); else mg_gemm_debug_profile(buf);
+        if (gv == 5) mg_gemm5_debug_profile(buf); else mg_gemm_debug_profile(buf);
         test_gemm(75600, 5120, 5120, 0, 64, true);
         unsigned long long h[32];
         CK(hipMemcpy(h, buf, sizeof h, hipMemcpyDeviceToHost));
@@ -544,7 +543,6 @@ int main(int argc, char** argv) {
                    h[w * 4] / n, h[w * 4 + 1] / n, h[w * 4 + 2] / n);
         }
         mg_gemm_debug_profile(nullptr);
-        mg_gemm3_debug_profile(nullptr);
         mg_gemm5_debug_profile(nullptr);
         return 0;
     }
@@ -553,7 +551,7 @@ int main(int argc, char** argv) {
         return n_fail ? 1 : 0;
     }
     if (argc > 1 && !strcmp(argv[1], "gemm")) {
-        for (int variant : {1, 2, 3, 5}) {
+        for (int variant : {1, 2, 5}) {
             printf("== gemm variant %d ==\n", variant);
             mg_gemm_set_variant(variant);
             for (int epi = 0; epi < 4; ++epi) test_gemm(300, 256, 128, epi, 0, false);

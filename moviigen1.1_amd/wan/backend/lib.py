@@ -47,13 +47,21 @@ SIGNATURES = {
     'mg_vae_time_interleave_f32': [c_vp, c_int, c_i64, c_int, c_vp, c_vp],
     'mg_video_to_u8': [c_vp, c_int, c_int, c_int, c_f32, c_f32, c_vp, c_vp],
     'mg_gate_residual_f32': [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int, c_vp],
+    # debug / profiling hooks (declared in the header's last section; never called by the product path)
+    'mg_attn_debug_profile': [c_vp],
+    'mg_attn_w64_profile': [c_vp],
+    'mg_attn_w64_debug': [c_int],
+    'mg_gemm_debug_profile': [c_vp],
+    'mg_gemm5_debug_profile': [c_vp],
     'mg_image_to_u8': [c_vp, c_int, c_int, c_f32, c_f32, c_vp, c_vp],
     'mg_sp_pack_qkv_bf16': [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_int, c_vp, c_vp],
     'mg_sp_copy_blocks_bf16': [c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_int, c_i64, c_int, c_vp],
     'mg_sp_unpack_o_bf16': [c_vp, c_i64, c_int, c_int, c_int, c_int, c_vp, c_i64, c_vp],
 }
 _RESTYPE = {'mg_version': ctypes.c_char_p, 'mg_attn_set_lazy_rescale': None, 'mg_attn_set_variant': None,
-            'mg_gemm_set_variant': None}
+            'mg_gemm_set_variant': None, 'mg_attn_debug_profile': None, 'mg_attn_w64_profile': None,
+            'mg_attn_w64_debug': None, 'mg_gemm_debug_profile': None, 'mg_gemm5_debug_profile': None}
+DEFAULT_GEMM_VARIANT = 5   # must match g_gemm_variant in csrc/gemm_bf16.hip
 
 ERRORS = {-1: 'MG_ERR_ARG (null pointer / bad enum)', -2: 'MG_ERR_SHAPE (unsupported shape or alignment)',
           -3: 'MG_ERR_LAUNCH (kernel launch failed)'}

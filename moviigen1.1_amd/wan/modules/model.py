@@ -348,7 +348,7 @@ class WanModel(nn.Module):
         return (1, self.sp_size) if self.ring else (self.sp_size, 1)
 
     def _workspace(self, L, dev):
-        key = (L, str(dev))
+        key = (L, str(dev), self.sp_force, self.sp_size, self._sp_layout())
         ws = self._ws.get(key)
         if ws is None:
             d, f = self.dim, self.ffn_dim

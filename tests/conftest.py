@@ -33,3 +33,19 @@ def golden():
     def load(name):
         return dict(np.load(os.path.join(GOLDEN, name + '.npz')))
     return load
+
+
+@pytest.fixture(autouse=True)
+def _reset_kernel_selection(request):
+    """mg_attn_set_variant / mg_gemm_set_variant / the debug hooks are process-global test switches: whatever a GPU
+    test selected is undone after it, so no test can change the launches of a later one."""
+    yield
+    if 'gpu' not in request.keywords:
+        return
+    from wan.backend import lib
+    h = lib._lib
+    if h is not None:
+        h.mg_attn_set_variant(lib.DEFAULT_ATTN_VARIANT)
+        h.mg_gemm_set_variant(lib.DEFAULT_GEMM_VARIANT)
+        h.mg_attn_set_lazy_rescale(1)
+        h.mg_attn_w64_debug(0)

@@ -125,14 +125,14 @@ def test_gemm_epilogues(dev, M, N, K, epi):
 
 @pytest.mark.parametrize('M,N,K', [(700, 520, 256), (257, 132, 64), (1030, 1284, 640)])
 def test_gemm_tile_variants_agree(dev, M, N, K):
-    """the four tile schedules (128x128, 256x128, 256x256 with 8 or 4 waves) give the same bits, ragged edges included."""
+    """the three tile schedules (128x128, 256x128, 256x256 with one wave per SIMD) give the same bits, ragged edges included."""
     from wan.backend import lib, ops
     a = W.randn((M, K), 16).bfloat16().to(dev)
     w = (W.randn((N, K), 17) * 0.05).bfloat16().to(dev)
     b = W.randn((N,), 18).to(dev)
     outs = []
     try:
-        for v in (1, 2, 3, 5):
+        for v in (1, 2, 5):
             lib.load().mg_gemm_set_variant(v)
             o = torch.full((M + 1, N), -7.0, dtype=torch.float32, device=dev)      # guard row: no write past M
             ops.gemm(a, w, b, ops.BIAS_F32, o[:M])

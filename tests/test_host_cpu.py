@@ -26,8 +26,13 @@ def test_cabi_exports_every_declared_symbol():
     handle = lib.load()
     for name in declared:
         assert hasattr(handle, name), name
-    assert handle.mg_abi_version() == 2
+    assert handle.mg_abi_version() == 3
     assert b'gfx950' in handle.mg_version()
+    # and nothing undeclared leaks out of the .so: every exported mg_* symbol is in the header
+    import subprocess
+    nm = subprocess.run(['nm', '-D', '--defined-only', lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r'\bT (mg_[a-z0-9_]+)$', nm, re.M))
+    assert exported and exported <= declared, exported - declared
 
 
 def test_product_never_imports_oracle():
