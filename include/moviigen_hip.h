@@ -99,6 +99,8 @@ int mg_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw,
  * the drop-in contract and not thread-safe; the default (5) already selects by shape:
  * 5 (default) = 256x256x64 tile, 4 waves = ONE per SIMD (128x128 each, accumulators in AGPRs), 2 LDS
  *     stages, LDS-DMA pieces and fragment reads spread between the MFMAs (M > 256 and N > 128, else 2);
+ * 6 = the same tile and k-loop as 5 in a persistent loop (one workgroup per CU; the first k-tile of the next tile is
+ *     fetched during the last k-tile of the current one, so it is in flight under the epilogue);
  * 2 = 256x128x64 tile, 8 waves, 3-stage LDS ring with counted vmcnt (M > 128, else 1);
  * 1 = 128x128x64 tile, 4 waves, 2 stages. */
 void mg_gemm_set_variant(int variant);

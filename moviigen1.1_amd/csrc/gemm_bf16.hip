@@ -136,6 +136,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(
 
 int mg_gemm_v5_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_t ldw, const float* bias, int64_t M,
                       int N, int K, int epilogue, void* out, int64_t ldo, const float* gate, hipStream_t st);
+int mg_gemm_v6_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_t ldw, const float* bias, int64_t M,
+                      int N, int K, int epilogue, void* out, int64_t ldo, const float* gate, hipStream_t st);
 int mg_gemm_v2_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_t ldw, const float* bias, int64_t M,
                       int N, int K, int epilogue, void* out, int64_t ldo, const float* gate, hipStream_t st);
 
@@ -156,6 +158,8 @@ extern "C" int mg_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* Wt, 
     if (bias && ((uintptr_t)bias & 15)) return MG_ERR_SHAPE;
     if (gate && ((uintptr_t)gate & 15)) return MG_ERR_SHAPE;
     if (M == 0) return MG_OK;
+    if (g_gemm_variant == 6 && M > 256 && N > 128)
+        return mg_gemm_v6_launch(A, lda, Wt, ldw, bias, M, N, K, epilogue, out, ldo, gate, (hipStream_t)stream);
     if (g_gemm_variant == 5 && M > 256 && N > 128)
         return mg_gemm_v5_launch(A, lda, Wt, ldw, bias, M, N, K, epilogue, out, ldo, gate, (hipStream_t)stream);
     if (g_gemm_variant >= 2 && M > 128)  // tiny M: the 128-row tile wastes less (variant 5 falls through to here for narrow shapes)

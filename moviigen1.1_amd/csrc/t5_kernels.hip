@@ -28,8 +28,21 @@ extern "C" int mg_embed_rows_bf16(const uint16_t* table, int64_t vocab, int dim,
     return mg_check_launch();
 }
 
+// the reference's GELU module is a chain of bf16 elementwise ops (t5.py:46-50), each of which rounds its result:
+// pow(x,3), *0.044715, +x, *sqrt(2/pi), tanh, 1+, 0.5*x, * — restated with the same rounding points
+MG_DEV float t5_gelu_bf16_chain(float x) {
+    const float p = round_bf(x * x * x);
+    const float m = round_bf(0.044715f * p);
+    const float s = round_bf(x + m);
+    const float u = round_bf(0.7978845608028654f * s);
+    const float e = __expf(2.f * u);
+    const float th = round_bf(1.f - 2.f / (e + 1.f));
+    const float o = round_bf(1.f + th);
+    return round_bf((0.5f * x) * o);
+}
+
 // mode 0: out = bf16(a + b)                                  residual add of bf16 tensors (t5.py:165-166)
-// mode 1: out = bf16(a * gelu_tanh(b))                       T5FeedForward: fc1(x) * gate(x) (t5.py:135)
+// mode 1: out = bf16(a * gelu(b))                            T5FeedForward: fc1(x) * gate(x) (t5.py:135)
 __global__ void t5_ew_kernel(const uint16_t* __restrict__ a, const uint16_t* __restrict__ b,
                              uint16_t* __restrict__ out, int64_t n8, int mode) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
@@ -38,7 +51,7 @@ __global__ void t5_ew_kernel(const uint16_t* __restrict__ a, const uint16_t* __r
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float x = bf2f(ua[j]), y = bf2f(ub[j]);
-            r[j] = mode == 0 ? x + y : x * round_bf(gelu_tanh(y));
+            r[j] = mode == 0 ? x + y : x * t5_gelu_bf16_chain(y);
         }
         u32x4_t o;
 #pragma unroll

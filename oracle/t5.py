@@ -65,7 +65,10 @@ def t5_attention(P, pre, x, bias, klen, heads, bf):
 
 def t5_ffn(P, pre, x, bf):
     g = _lin(x, P[pre + 'gate.0.weight'], bf)
-    g = _bf(0.5 * g * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (g + 0.044715 * torch.pow(g, 3.0)))), bf)
+    # GELU (t5.py:46-50) is a chain of elementwise ops: in the bf16 deployment dtype EVERY one of them rounds
+    r = lambda v: _bf(v, bf)  # noqa: E731
+    inner = r(math.sqrt(2.0 / math.pi) * r(g + r(0.044715 * r(torch.pow(g, 3.0)))))
+    g = r(r(0.5 * g) * r(1.0 + r(torch.tanh(inner))))
     h = _bf(_lin(x, P[pre + 'fc1.weight'], bf) * g, bf)
     return _lin(h, P[pre + 'fc2.weight'], bf)
 

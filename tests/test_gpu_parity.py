@@ -123,16 +123,17 @@ def test_gemm_epilogues(dev, M, N, K, epi):
     assert scale_err(out.float(), ref) < 1.2e-2
 
 
-@pytest.mark.parametrize('M,N,K', [(700, 520, 256), (257, 132, 64), (1030, 1284, 640)])
+@pytest.mark.parametrize('M,N,K', [(700, 520, 256), (257, 132, 64), (1030, 1284, 640), (4200, 4100, 128), (9000, 2304, 64)])
 def test_gemm_tile_variants_agree(dev, M, N, K):
-    """the three tile schedules (128x128, 256x128, 256x256 with one wave per SIMD) give the same bits, ragged edges included."""
+    """the tile schedules (128x128, 256x128, 256x256 with one wave per SIMD: one tile per workgroup, and the persistent
+    tile loop — the last two shapes have more tiles than CUs, so its workgroups iterate) give the same bits, ragged edges included."""
     from wan.backend import lib, ops
     a = W.randn((M, K), 16).bfloat16().to(dev)
     w = (W.randn((N, K), 17) * 0.05).bfloat16().to(dev)
     b = W.randn((N,), 18).to(dev)
     outs = []
     try:
-        for v in (1, 2, 5):
+        for v in (1, 2, 5, 6):
             lib.load().mg_gemm_set_variant(v)
             o = torch.full((M + 1, N), -7.0, dtype=torch.float32, device=dev)      # guard row: no write past M
             ops.gemm(a, w, b, ops.BIAS_F32, o[:M])
