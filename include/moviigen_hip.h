@@ -30,6 +30,8 @@ extern "C" {
 #define MG_ERR_ARG (-1)    /* null pointer / bad enum */
 #define MG_ERR_SHAPE (-2)  /* unsupported shape or alignment */
 #define MG_ERR_LAUNCH (-3) /* hipGetLastError() != hipSuccess after launch */
+#define MG_ERR_UNAVAILABLE (-4) /* librccl could not be bound at run time (collective entry points only) */
+#define MG_ERR_COMM (-5) /* an RCCL call returned an error */
 
 /* library identification: returns a static string "moviigen_hip <abi> gfx950" */
 const char* mg_version(void);
@@ -158,6 +160,40 @@ int mg_sp_unpack_o_bf16(const uint16_t* recv, int64_t Lloc, int P, int cols_per_
  * everything % 8 == 0, 16-byte aligned. */
 int mg_sp_copy_blocks_bf16(const uint16_t* src, int64_t s_blk, int64_t s_row, uint16_t* dst, int64_t d_blk,
                            int64_t d_row, int blocks, int64_t rows, int width, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Collectives on an RCCL communicator.  librccl is bound at run time (dlopen, preferring the
+ * copy already loaded in the process); without it these return MG_ERR_UNAVAILABLE and nothing else is affected.
+ * `comm` is an ncclComm_t.  Everything is enqueued on `stream`; no host synchronisation.
+ * Replaces: xfuser get_sp_group().all_gather / xFuserLongContextAttention's all-to-alls
+ * (wan/distributed/xdit_context_parallel.py:148,185-190), FastVideo all_to_all_4D / all_gather
+ * (scripts/train/model/model_seq.py:232-234,256,780), torch FSDP's per-block parameter all-gather
+ * (wan/distributed/fsdp.py:20-31).
+ * ---------------------------------------------------------------------------------------- */
+
+/* communicator bootstrap: rank 0 calls mg_comm_unique_id (128 bytes), hands the bytes to every rank by any side
+ * channel (the host code uses torch.distributed's object broadcast), every rank calls mg_comm_create. */
+int mg_comm_unique_id(void* id128);
+int mg_comm_create(const void* id128, int nranks, int rank, void** comm);
+int mg_comm_destroy(void* comm);
+
+/* all-to-all of equal chunks: bytes [p*B, (p+1)*B) of `send` go to rank p, the same range of `recv` comes from rank p
+ * (B = bytes_per_peer).  Grouped ncclSend/ncclRecv: on the xGMI mesh every pair uses its own link. */
+int mg_sp_all_to_all(void* comm, const void* send, void* recv, int64_t bytes_per_peer, void* stream);
+
+/* FastVideo's all_to_all_4D on one bf16 tensor, layout changes included:
+ *   seq_to_head != 0 (scatter_dim=2, gather_dim=1): x [rows = L/P][heads*head_dim] (row stride ldx)
+ *        -> out [L][(heads/P)*head_dim] contiguous (ldo must equal (heads/P)*head_dim), tokens in rank order;
+ *   seq_to_head == 0 (scatter_dim=1, gather_dim=2): x [rows = L][(heads/P)*head_dim] contiguous
+ *        -> out [L/P][heads*head_dim] (row stride ldo).
+ * workspace: rows * (heads/P or heads... i.e. as many elements as x) bf16, 16-byte aligned. */
+int mg_sp_all_to_all_4d_bf16(void* comm, const uint16_t* x, int64_t ldx, int64_t rows, int heads, int head_dim,
+                             int seq_to_head, uint16_t* out, int64_t ldo, uint16_t* workspace, void* stream);
+
+/* rank-order concatenation of `bytes` bytes per rank (ncclAllGather): the head-output gather of the SP forward and the
+ * per-block parameter gather of the block-sharded (FSDP-style) weights. */
+int mg_sp_all_gather(void* comm, const void* send, void* recv, int64_t bytes, void* stream);
+int mg_shard_all_gather(void* comm, const void* shard, void* full, int64_t shard_bytes, void* stream);
 
 /* Ring attention (the reference delegates to yunchang inside xFuserLongContextAttention,
  * generate.py:225-229): fold one block's normalised bf16 result `part` [Lq][heads*128] and its lse into

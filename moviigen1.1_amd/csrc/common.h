@@ -8,6 +8,8 @@
 #define MG_ERR_ARG (-1)
 #define MG_ERR_SHAPE (-2)
 #define MG_ERR_LAUNCH (-3)
+#define MG_ERR_UNAVAILABLE (-4)   // librccl could not be bound at run time
+#define MG_ERR_COMM (-5)          // an RCCL call failed
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(8))) unsigned short u16x8_t;

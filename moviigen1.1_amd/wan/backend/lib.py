@@ -46,6 +46,13 @@ SIGNATURES = {
     'mg_vae_video_out_f32': [c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_int, c_vp],
     'mg_vae_time_interleave_f32': [c_vp, c_int, c_i64, c_int, c_vp, c_vp],
     'mg_video_to_u8': [c_vp, c_int, c_int, c_int, c_f32, c_f32, c_vp, c_vp],
+    'mg_comm_unique_id': [c_vp],
+    'mg_comm_create': [c_vp, c_int, c_int, c_vp],
+    'mg_comm_destroy': [c_vp],
+    'mg_sp_all_to_all': [c_vp, c_vp, c_vp, c_i64, c_vp],
+    'mg_sp_all_to_all_4d_bf16': [c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_vp],
+    'mg_sp_all_gather': [c_vp, c_vp, c_vp, c_i64, c_vp],
+    'mg_shard_all_gather': [c_vp, c_vp, c_vp, c_i64, c_vp],
     'mg_gate_residual_f32': [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int, c_vp],
     # debug / profiling hooks (declared in the header's last section; never called by the product path)
     'mg_attn_debug_profile': [c_vp],
@@ -64,7 +71,8 @@ _RESTYPE = {'mg_version': ctypes.c_char_p, 'mg_attn_set_lazy_rescale': None, 'mg
 DEFAULT_GEMM_VARIANT = 5   # must match g_gemm_variant in csrc/gemm_bf16.hip
 
 ERRORS = {-1: 'MG_ERR_ARG (null pointer / bad enum)', -2: 'MG_ERR_SHAPE (unsupported shape or alignment)',
-          -3: 'MG_ERR_LAUNCH (kernel launch failed)'}
+          -3: 'MG_ERR_LAUNCH (kernel launch failed)', -4: 'MG_ERR_UNAVAILABLE (librccl could not be bound)',
+          -5: 'MG_ERR_COMM (an RCCL call failed)'}
 
 _lib = None
 DEFAULT_ATTN_VARIANT = 0   # must match g_attn_variant in csrc/attn_hd128.hip

@@ -90,7 +90,10 @@ class BlockShards:
     def _gather(self, i, slot):
         shard = self.shards[i]
         out = self.bufs[slot][:shard.numel() * self.P]
-        if self.staged and shard.is_cuda:
+        from . import rccl_direct
+        if shard.is_cuda and not self.staged and rccl_direct.enabled():
+            rccl_direct.comm_for(self.group).all_gather(out, shard)          # mg_shard_all_gather on the comm stream
+        elif self.staged and shard.is_cuda:
             parts = [torch.empty(shard.shape, dtype=shard.dtype) for _ in range(self.P)]
             dist.all_gather(parts, shard.cpu(), group=self.group)
             out.copy_(torch.cat(parts))

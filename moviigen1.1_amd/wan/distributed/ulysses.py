@@ -34,10 +34,13 @@ import torch
 import torch.distributed as dist
 
 from ..backend import ops
+from . import rccl_direct
 
 
 def _a2a(recv, send, group):
-    if send.is_cuda and dist.get_backend(group) == 'gloo':
+    if send.is_cuda and rccl_direct.enabled() and dist.get_backend(group) != 'gloo':
+        rccl_direct.comm_for(group).all_to_all(recv, send)      # C-ABI collective on the library's own communicator
+    elif send.is_cuda and dist.get_backend(group) == 'gloo':
         s, r = send.cpu(), torch.empty(recv.shape, dtype=recv.dtype)
         dist.all_to_all_single(r, s, group=group)
         recv.copy_(r)
@@ -142,7 +145,9 @@ def head_to_seq(x, out, group, P, heads, head_dim):
 def all_gather_seq(x, group, P):
     """x [Lloc, C] -> [P*Lloc, C] (rank-order concatenation; get_sp_group().all_gather(dim=1))."""
     out = torch.empty(P * x.shape[0], x.shape[1], dtype=x.dtype, device=x.device)
-    if x.is_cuda and dist.get_backend(group) == 'gloo':
+    if x.is_cuda and rccl_direct.enabled() and dist.get_backend(group) != 'gloo':
+        rccl_direct.comm_for(group).all_gather(out, x.contiguous())
+    elif x.is_cuda and dist.get_backend(group) == 'gloo':
         parts = [torch.empty(x.shape, dtype=x.dtype) for _ in range(P)]
         dist.all_gather(parts, x.cpu().contiguous(), group=group)
         out.copy_(torch.cat(parts, 0))

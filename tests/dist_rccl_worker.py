@@ -49,9 +49,32 @@ m.sp_force = True                       # take the Ulysses branch on the size-1 
 got = m([lat], t=t, context=[ctx], seq_len=32)[0]
 assert torch.equal(got, ref), (got - ref).abs().max().item()
 print('RCCL_SP_BRANCH_OK', flush=True)
+# ---- the C-ABI collectives on the library's own RCCL communicator (include/moviigen_hip.h: mg_comm_*, mg_sp_*) --------
+from wan.distributed import rccl_direct  # noqa: E402
+dc = rccl_direct.DirectComm()
+assert dc.size == 1 and dc.rank == 0 and dc.handle
+xs = torch.randn(L, N * hd, device=dev).bfloat16()
+r1 = torch.empty_like(xs)
+dc.all_to_all(r1, xs)
+wsb = torch.empty_like(xs)
+o4 = torch.empty(L, N * hd, dtype=torch.bfloat16, device=dev)
+dc.all_to_all_4d(x[:, N * hd:2 * N * hd], o4, N, hd, True, wsb)          # strided source (k slice of a fused qkv buffer)
+b4 = torch.empty(L, 3 * N * hd, dtype=torch.bfloat16, device=dev)
+dc.all_to_all_4d(o4, b4[:, :N * hd], N, hd, False, wsb)                     # strided destination
+g1 = torch.empty_like(xs)
+dc.all_gather(g1, xs)
+torch.cuda.synchronize()
+assert torch.equal(r1, xs) and torch.equal(o4, x[:, N * hd:2 * N * hd]) and torch.equal(b4[:, :N * hd], o4) and torch.equal(g1, xs)
+os.environ['MOVIIGEN_SP_TRANSPORT'] = 'rccl_direct'
+m._ws = {}
+got = m([lat], t=t, context=[ctx], seq_len=32)[0]                          # sp_force is still on: exchange via mg_sp_all_to_all
+assert torch.equal(got, ref), (got - ref).abs().max().item()
+print('RCCL_DIRECT_OK', flush=True)
 m.sp_force = False
 m = fsdp.shard_model(m, device_id=0)
 got = m([lat], t=t, context=[ctx], seq_len=32)[0]
 assert torch.equal(got, ref)
 print('RCCL_FSDP_OK', flush=True)
+os.environ.pop('MOVIIGEN_SP_TRANSPORT')
+dc.destroy()
 dist.destroy_process_group()

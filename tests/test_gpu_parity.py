@@ -737,12 +737,14 @@ def test_cfg_parallel_one_gpu(world):
         assert f'CFGP_OK rank{k}/{world}' in r.stdout
 
 
-def _run_hybrid(world, backend, layout, port):
+def _run_hybrid(world, backend, layout, port, transport='torch'):
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MOVIIGEN_TEST_BACKEND=backend, MOVIIGEN_TEST_LAYOUT=layout, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    if transport == 'rccl_direct':      # the C-ABI collectives on the library's own communicator (mg_sp_all_to_all, ...)
+        env['MOVIIGEN_SP_TRANSPORT'] = 'rccl_direct'
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={world}',
                         '--master-addr', '127.0.0.1', '--master-port', str(port),
                         os.path.join(root, 'tests', 'dist_hybrid_worker.py')], capture_output=True, text=True, timeout=900,
@@ -760,15 +762,16 @@ def test_config3_composition_one_gpu(world, layout):
     _run_hybrid(world, 'gloo', layout, 29600 + world + (0 if layout == 'cfg_sp_fsdp' else 10))
 
 
+@pytest.mark.parametrize('transport', ['torch', 'rccl_direct'])
 @pytest.mark.parametrize('layout', ['cfg_sp_fsdp', 'sp_fsdp'])
-def test_rccl_multi_gpu(layout):
+def test_rccl_multi_gpu(layout, transport):
     """the production transport with MORE than one rank: backend nccl (= RCCL over xGMI), one rank per visible GPU
     (2, 4 or 8), exchange on the communication stream overlapped with attention.  Skipped on a 1-GPU box."""
     n = torch.cuda.device_count()
     if n < 2:
         pytest.skip('needs >= 2 GPUs (RCCL refuses two ranks on one device)')
     world = 8 if n >= 8 else 4 if n >= 4 else 2
-    _run_hybrid(world, 'nccl', layout, 29630 + world)
+    _run_hybrid(world, 'nccl', layout, 29630 + world + (20 if transport == 'rccl_direct' else 0), transport)
 
 
 def test_train_side_sp_forward_one_gpu():
@@ -967,7 +970,7 @@ def test_rccl_backend_single_rank():
     r = subprocess.run([sys.executable, os.path.join(root, 'tests', 'dist_rccl_worker.py')], capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    for tag in ('RCCL_COLLECTIVES_OK', 'RCCL_SP_BRANCH_OK', 'RCCL_FSDP_OK'):
+    for tag in ('RCCL_COLLECTIVES_OK', 'RCCL_SP_BRANCH_OK', 'RCCL_DIRECT_OK', 'RCCL_FSDP_OK'):
         assert tag in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
