@@ -306,8 +306,10 @@ int mg_vae_rmsnorm_silu_f32(const float* x, const float* gamma, float* out, int6
 
 /* Single-head attention over one frame's h*w tokens with head dim C (<=512, %32==0), fp32:
  * AttentionBlock, vae.py:247-256 (scaled_dot_product_attention, scale 1/sqrt(C)).
- * qkv [frames][L][3C] (q|k|v), out [frames][L][C]; workspace: caller-owned (L + C) * roundup(L, 4)
- * floats, 16-byte aligned (the library never allocates). */
+ * qkv [frames][L][3C] (q|k|v), out [frames][L][C]; workspace: caller-owned, mg_vae_attn_workspace_floats(L, C)
+ * floats = (min(L, 2048) + C) * roundup(L, 4) — one block of 2048 query rows of the score matrix, which stays
+ * inside the Infinity Cache between the three passes, plus V^T — 16-byte aligned (the library never allocates). */
+int64_t mg_vae_attn_workspace_floats(int64_t L, int C);
 int mg_vae_attn_f32(const float* qkv, float* out, int frames, int64_t L, int C, float* workspace,
                     void* stream);
 

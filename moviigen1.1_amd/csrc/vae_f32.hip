@@ -291,6 +291,17 @@ __global__ void transpose_f32_kernel(const float* __restrict__ in, int64_t ldin,
     }
 }
 
+// queries are processed in blocks of VAE_ATTN_QB rows: the score block S [QB][L] (204 MB at L = 24 960) stays inside the
+// 256 MB Infinity Cache between the GEMM that writes it, the three softmax sweeps and the GEMM that reads it, and the
+// workspace is (QB + C) * L floats instead of the full L x L matrix (2.5 GB at 1920x832).  Same arithmetic per row.
+#define VAE_ATTN_QB 2048
+
+extern "C" int64_t mg_vae_attn_workspace_floats(int64_t L, int C) {
+    const int64_t Lp = (L + 3) & ~(int64_t)3;
+    const int64_t qb = L < VAE_ATTN_QB ? L : VAE_ATTN_QB;
+    return (qb + C) * Lp;
+}
+
 extern "C" int mg_vae_attn_f32(const float* qkv, float* out, int frames, int64_t L, int C, float* workspace,
                                void* stream) {
     if (!qkv || !out || !workspace) return MG_ERR_ARG;
@@ -298,26 +309,30 @@ extern "C" int mg_vae_attn_f32(const float* qkv, float* out, int frames, int64_t
     if ((uintptr_t)workspace & 15) return MG_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     const int64_t Lp = (L + 3) & ~(int64_t)3;  // row stride of S / V^T, 16-byte aligned rows
-    float* S = workspace;                 // [L][Lp]
-    float* vT = workspace + L * Lp;       // [C][Lp]
+    const int64_t QB = L < VAE_ATTN_QB ? L : VAE_ATTN_QB;
+    float* S = workspace;                 // [QB][Lp]
+    float* vT = workspace + QB * Lp;      // [C][Lp]
     for (int f = 0; f < frames; ++f) {
         const float* base = qkv + (int64_t)f * L * 3 * C;
-        ConvArgs a;
-        // S[L][L] = q[L][C] . k[L][C]^T * C^-1/2
-        a.x = base; a.cache = nullptr; a.tc = 0; a.T = 1; a.H = 1; a.W = (int)L; a.Cin = C; a.ldx = 3 * C;
-        a.w = base + C; a.ldw = 3 * C; a.bias = nullptr; a.Cout = (int)L; a.kt = a.kh = a.kw = 1; a.up2 = 0;
-        a.residual = nullptr; a.out = S; a.ldo = Lp; a.Ho = 1; a.Wo = (int)L; a.M = L;
-        a.out_scale = 1.f / sqrtf((float)C);
-        int rc = launch_conv(a, st);
-        if (rc) return rc;
-        hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)L), dim3(256), 0, st, S, L, Lp);
         hipLaunchKernelGGL(transpose_f32_kernel, dim3((unsigned)((Lp + 31) / 32), (unsigned)((C + 31) / 32)),
                            dim3(32, 8), 0, st, base + 2 * C, (int64_t)3 * C, vT, L, C, Lp);
-        // out[L][C] = P[L][Lp] . vT[C][Lp]^T   (padding columns are zero on both sides)
-        a.x = S; a.ldx = Lp; a.Cin = (int)Lp; a.w = vT; a.ldw = Lp; a.Cout = C; a.out = out + (int64_t)f * L * C;
-        a.ldo = C; a.out_scale = 1.f;
-        rc = launch_conv(a, st);
-        if (rc) return rc;
+        for (int64_t q0 = 0; q0 < L; q0 += QB) {
+            const int64_t nq = L - q0 < QB ? L - q0 : QB;
+            ConvArgs a;
+            // S[nq][L] = q[q0.. ][C] . k[L][C]^T * C^-1/2
+            a.x = base + q0 * 3 * C; a.cache = nullptr; a.tc = 0; a.T = 1; a.H = 1; a.W = (int)nq; a.Cin = C; a.ldx = 3 * C;
+            a.w = base + C; a.ldw = 3 * C; a.bias = nullptr; a.Cout = (int)L; a.kt = a.kh = a.kw = 1; a.up2 = 0;
+            a.residual = nullptr; a.out = S; a.ldo = Lp; a.Ho = 1; a.Wo = (int)nq; a.M = nq;
+            a.out_scale = 1.f / sqrtf((float)C);
+            int rc = launch_conv(a, st);
+            if (rc) return rc;
+            hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)nq), dim3(256), 0, st, S, L, Lp);
+            // out[nq][C] = P[nq][Lp] . vT[C][Lp]^T   (padding columns are zero on both sides)
+            a.x = S; a.ldx = Lp; a.Cin = (int)Lp; a.w = vT; a.ldw = Lp; a.Cout = C; a.out = out + ((int64_t)f * L + q0) * C;
+            a.ldo = C; a.out_scale = 1.f;
+            rc = launch_conv(a, st);
+            if (rc) return rc;
+        }
     }
     return mg_check_launch();
 }

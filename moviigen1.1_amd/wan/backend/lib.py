@@ -41,6 +41,7 @@ SIGNATURES = {
     'mg_vae_conv_f32': [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int,
                         c_int, c_vp, c_vp, c_vp],
     'mg_vae_rmsnorm_silu_f32': [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp],
+    'mg_vae_attn_workspace_floats': [c_i64, c_int],
     'mg_vae_attn_f32': [c_vp, c_vp, c_int, c_i64, c_int, c_vp, c_vp],
     'mg_vae_latent_in_f32': [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp],
     'mg_vae_video_out_f32': [c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_int, c_vp],
@@ -65,7 +66,7 @@ SIGNATURES = {
     'mg_sp_copy_blocks_bf16': [c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_int, c_i64, c_int, c_vp],
     'mg_sp_unpack_o_bf16': [c_vp, c_i64, c_int, c_int, c_int, c_int, c_vp, c_i64, c_vp],
 }
-_RESTYPE = {'mg_version': ctypes.c_char_p, 'mg_attn_set_lazy_rescale': None, 'mg_attn_set_variant': None,
+_RESTYPE = {'mg_version': ctypes.c_char_p, 'mg_vae_attn_workspace_floats': ctypes.c_int64, 'mg_attn_set_lazy_rescale': None, 'mg_attn_set_variant': None,
             'mg_gemm_set_variant': None, 'mg_attn_debug_profile': None, 'mg_attn_w64_profile': None,
             'mg_attn_w64_debug': None, 'mg_gemm_debug_profile': None, 'mg_gemm5_debug_profile': None}
 DEFAULT_GEMM_VARIANT = 5   # must match g_gemm_variant in csrc/gemm_bf16.hip

@@ -204,8 +204,14 @@ def vae_rmsnorm_silu(x, gamma, out, do_silu=True):
     return out
 
 
+def vae_attn_workspace_floats(L, C):
+    return int(lib.load().mg_vae_attn_workspace_floats(int(L), int(C)))
+
+
 def vae_attn(qkv, out, workspace):
     frames, L, C3 = qkv.shape
+    if workspace.numel() < vae_attn_workspace_floats(L, C3 // 3):
+        raise lib.MoviigenHipError('vae_attn workspace too small')
     lib.call('mg_vae_attn_f32', _p(qkv), _p(out), frames, L, C3 // 3, _p(workspace), _st())
     return out
 

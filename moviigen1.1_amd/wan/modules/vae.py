@@ -103,7 +103,7 @@ class WanVAE_:
         y = self._norm_silu(x, pre + 'norm.gamma', silu=False)
         qkv = self._conv(pre + 'to_qkv', y)
         a = self._new(T, H, W, C)
-        ws = self._new((L + C) * ((L + 3) // 4 * 4))
+        ws = self._new(ops.vae_attn_workspace_floats(L, C))
         ops.vae_attn(qkv.view(T, L, 3 * C), a.view(T, L, C), ws)
         return self._conv(pre + 'proj', a, residual=x)
 

@@ -455,6 +455,22 @@ def test_vae_modules_vs_oracle(dev, golden):
 # ------------------------------------------------------------------------------------------------
 # BASELINE.json configs[0] end to end through WanT2V.generate
 # ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('L,C', [(3000, 32), (5001, 96), (700, 384)])
+def test_vae_attention_query_blocks(dev, L, C):
+    """AttentionBlock arithmetic (vae.py:247-256) with more tokens than one 2048-row query block of the score
+    workspace (and a ragged last block): fp32 single-head softmax attention vs an fp64 evaluation."""
+    from wan.backend import ops
+    gen = torch.Generator(device=dev).manual_seed(L)
+    qkv = torch.randn(2, L, 3 * C, device=dev, generator=gen)
+    out = torch.empty(2, L, C, device=dev)
+    ws = torch.empty(ops.vae_attn_workspace_floats(L, C), device=dev)
+    assert ws.numel() <= (2048 + C) * (L + 3)
+    ops.vae_attn(qkv, out, ws)
+    q, k, v = qkv.double().split(C, dim=-1)
+    ref = torch.softmax(q @ k.transpose(1, 2) / math.sqrt(C), -1) @ v
+    assert ((out.double() - ref).abs().max() / ref.abs().max()).item() < 1e-5
+
+
 @pytest.mark.parametrize('solver', ['unipc', 'dpm++'])
 def test_pipeline_cfg1(dev, golden, solver):
     import wan
