@@ -98,8 +98,9 @@ int mg_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw,
                  int64_t ldo, const float* gate, void* stream);
 
 /* Tile schedule of mg_gemm_bf16 (same results bit for bit) — a process-global MEASUREMENT / TEST switch, not part of
- * the drop-in contract and not thread-safe; the default (5) already selects by shape:
- * 5 (default) = 256x256x64 tile, 4 waves = ONE per SIMD (128x128 each, accumulators in AGPRs), 2 LDS
+ * the drop-in contract and not thread-safe; the default (0) selects by shape and epilogue (6 where the epilogue
+ * only stores, 5 for the residual epilogue, 2 / 1 for narrow shapes):
+ * 5 = 256x256x64 tile, 4 waves = ONE per SIMD (128x128 each, accumulators in AGPRs), 2 LDS
  *     stages, LDS-DMA pieces and fragment reads spread between the MFMAs (M > 256 and N > 128, else 2);
  * 6 = the same tile and k-loop as 5 in a persistent loop (one workgroup per CU; the first k-tile of the next tile is
  *     fetched during the last k-tile of the current one, so it is in flight under the epilogue);

@@ -145,7 +145,7 @@ int mg_gemm_v2_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_
 // one per SIMD (gemm_bf16_v5.hip).  (3, the 8-wave 256x256 tile, was an A/B partner only: experiments/gemm_bf16_v3_8waves.hip.)
 // Process-global and NOT thread-safe on purpose: a measurement / test switch (tools/, tests/conftest.py resets it after
 // every test), never touched by the product path — mg_gemm_bf16 itself picks by shape.
-static int g_gemm_variant = 5;
+static int g_gemm_variant = 0;   // 0 = by shape AND epilogue (below)
 extern "C" void mg_gemm_set_variant(int v) { g_gemm_variant = v; }
 
 extern "C" int mg_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_t ldw,
@@ -158,11 +158,15 @@ extern "C" int mg_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* Wt, 
     if (bias && ((uintptr_t)bias & 15)) return MG_ERR_SHAPE;
     if (gate && ((uintptr_t)gate & 15)) return MG_ERR_SHAPE;
     if (M == 0) return MG_OK;
-    if (g_gemm_variant == 6 && M > 256 && N > 128)
+    // default: the persistent loop (6) wins where the epilogue only stores (r02c, M = 131 040: +1.8 % q|k|v, +3.3 % ffn.0,
+    // +1.7 % cross q) and loses 1.5 % on the residual epilogue, whose read-modify-write of x competes with the
+    // prefetch of the next tile — that one keeps one tile per workgroup (5)
+    const int variant = g_gemm_variant ? g_gemm_variant : (epilogue == MG_EPI_GATE_RESID_F32 ? 5 : 6);
+    if (variant == 6 && M > 256 && N > 128)
         return mg_gemm_v6_launch(A, lda, Wt, ldw, bias, M, N, K, epilogue, out, ldo, gate, (hipStream_t)stream);
-    if (g_gemm_variant == 5 && M > 256 && N > 128)
+    if (variant == 5 && M > 256 && N > 128)
         return mg_gemm_v5_launch(A, lda, Wt, ldw, bias, M, N, K, epilogue, out, ldo, gate, (hipStream_t)stream);
-    if (g_gemm_variant >= 2 && M > 128)  // tiny M: the 128-row tile wastes less (variant 5 falls through to here for narrow shapes)
+    if (variant >= 2 && M > 128)  // tiny M: the 128-row tile wastes less (variant 5 falls through to here for narrow shapes)
         return mg_gemm_v2_launch(A, lda, Wt, ldw, bias, M, N, K, epilogue, out, ldo, gate, (hipStream_t)stream);
     const int64_t tiles_m64 = (M + BM - 1) / BM;
     const int tiles_n = (N + BN - 1) / BN;

@@ -64,43 +64,66 @@ __global__ __launch_bounds__(CV_THREADS) void vae_conv_kernel(const ConvArgs a) 
     const int ntap = a.kt * a.kh * a.kw;
     const int nchunk = ntap * ncc;
 
+    // The gather is BRANCH-FREE: every lane always loads from a clamped, valid address and the result is zeroed by a
+    // select when the tap falls into the zero padding / before the first cached frame / past M (r02: the guarded
+    // version compiled to ~16 nested execz branches per chunk, which pinned all address arithmetic and loads in
+    // front of the MFMA block of the iteration — the matrix pipe idled 34 % of the time at full clock).  The chunk
+    // coordinates (tap -> dt, dy, dx; channel offset) advance by counters instead of divisions.
     float4 ra[4], rw[NB];
-    auto load_chunk = [&](int kc) {
-        const int tap = kc / ncc;
-        const int c = (kc - tap * ncc) * CV_BK + ch4 * 4;
-        const int dt = tap / (a.kh * a.kw);
-        const int dyx = tap - dt * a.kh * a.kw;
-        const int dy = dyx / a.kw, dx = dyx - dy * a.kw;
-        const bool c_ok = c < a.Cin;
+    float ka[4], kw_[NB];                                            // 0/1 masks of the loads in flight
+    int ld_cc = 0, ld_dt = 0, ld_dy = 0, ld_dx = 0, ld_tap = 0;     // coordinates of the NEXT chunk to load (wave-uniform)
+    const float* const base_neg = a.cache ? a.cache : a.x;          // frames before the chunk: the cache, if any
+    const int has_cache = a.cache != nullptr;
+    auto load_chunk = [&]() __attribute__((always_inline)) {
+        const int c_raw = ld_cc * CV_BK + ch4 * 4;
+        const int c_ok = c_raw < a.Cin;
+        const int c = c_ok ? c_raw : 0;
+        const int dt = ld_dt, dy = ld_dy, dx = ld_dx, tap = ld_tap;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             const int ti = vt_[i] + dt - (a.kt - 1);
             int yy = vy_[i] + dy - a.kh / 2, xx = vx_[i] + dx - a.kw / 2;
-            if (c_ok && vt_[i] >= 0 && yy >= 0 && yy < a.Ho && xx >= 0 && xx < a.Wo) {
-                if (a.up2) { yy >>= 1; xx >>= 1; }
-                const float* src = nullptr;
-                if (ti >= 0) src = a.x + (((int64_t)ti * a.H + yy) * a.W + xx) * a.ldx;
-                else if (a.tc + ti >= 0) src = a.cache + (((int64_t)(a.tc + ti) * a.H + yy) * a.W + xx) * a.ldx;
-                if (src) v = *(const float4*)(src + c);
-            }
-            ra[i] = v;
+            // bitwise on purpose: `&&` compiles to nested exec-mask branches here
+            const int ok = c_ok & (vt_[i] >= 0) & (yy >= 0) & (yy < a.Ho) & (xx >= 0) & (xx < a.Wo) &
+                           ((ti >= 0) | (has_cache & (a.tc + ti >= 0)));
+            yy = min(max(yy, 0), a.Ho - 1);
+            xx = min(max(xx, 0), a.Wo - 1);
+            if (a.up2) { yy >>= 1; xx >>= 1; }
+            const int tt = max(ti >= 0 ? ti : a.tc + ti, 0);          // (ti <= vt < T always: the taps only reach back in time)
+            const int vox = (tt * a.H + yy) * a.W + xx;               // < 2^31 voxels per launch (checked on the host)
+            const float* src = (ti >= 0 ? a.x : base_neg) + (int64_t)vox * a.ldx + c;
+            ra[i] = *(const float4*)src;
+            ka[i] = ok ? 1.f : 0.f;
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const int row = (tid >> 3) + 32 * i;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (c_ok && n0 + row < a.Cout) v = *(const float4*)(a.w + (int64_t)(n0 + row) * a.ldw + (int64_t)tap * a.Cin + c);
-            rw[i] = v;
+            const int row = n0 + (tid >> 3) + 32 * i;
+            rw[i] = *(const float4*)(a.w + (int64_t)min(row, a.Cout - 1) * a.ldw + (int64_t)tap * a.Cin + c);
+            kw_[i] = (c_ok & (row < a.Cout)) ? 1.f : 0.f;
+        }
+        if (++ld_cc == ncc) {
+            ld_cc = 0;
+            ++ld_tap;
+            if (++ld_dx == a.kw) {
+                ld_dx = 0;
+                if (++ld_dy == a.kh) { ld_dy = 0; ++ld_dt; }
+            }
         }
     };
-    auto store_chunk = [&](int buf) {
+    // the mask is applied HERE, behind the MFMAs of the iteration, so the loads have the whole compute phase to land.
+    // Multiplying (instead of selecting) keeps LLVM from sinking the loads back under the condition; the loaded values
+    // are finite tensor data from valid addresses, so v * 0 == 0 and v * 1 == v exactly.
+    auto store_chunk = [&](int buf) __attribute__((always_inline)) {
         float* sa = smem + buf * (CV_BM + BN) * CV_LDS;
         float* sw = sa + CV_BM * CV_LDS;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *(float4*)(sa + ((tid >> 3) + 32 * i) * CV_LDS + ch4 * 4) = ra[i];
+        for (int i = 0; i < 4; ++i)
+            *(float4*)(sa + ((tid >> 3) + 32 * i) * CV_LDS + ch4 * 4) =
+                make_float4(ra[i].x * ka[i], ra[i].y * ka[i], ra[i].z * ka[i], ra[i].w * ka[i]);
 #pragma unroll
-        for (int i = 0; i < NB; ++i) *(float4*)(sw + ((tid >> 3) + 32 * i) * CV_LDS + ch4 * 4) = rw[i];
+        for (int i = 0; i < NB; ++i)
+            *(float4*)(sw + ((tid >> 3) + 32 * i) * CV_LDS + ch4 * 4) =
+                make_float4(rw[i].x * kw_[i], rw[i].y * kw_[i], rw[i].z * kw_[i], rw[i].w * kw_[i]);
     };
 
     f32x16_t acc[NB];
@@ -109,11 +132,11 @@ __global__ __launch_bounds__(CV_THREADS) void vae_conv_kernel(const ConvArgs a) 
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
-    load_chunk(0);
+    load_chunk();
     store_chunk(0);
     __syncthreads();
     for (int kc = 0; kc < nchunk; ++kc) {
-        if (kc + 1 < nchunk) load_chunk(kc + 1);
+        if (kc + 1 < nchunk) load_chunk();
         const float* sa = smem + (kc & 1) * (CV_BM + BN) * CV_LDS + (wave * 32 + l31) * CV_LDS + g * 4;
         const float* sw = smem + (kc & 1) * (CV_BM + BN) * CV_LDS + CV_BM * CV_LDS + l31 * CV_LDS + g * 4;
 #pragma unroll
@@ -166,6 +189,7 @@ __global__ __launch_bounds__(CV_THREADS) void vae_conv_kernel(const ConvArgs a) 
 }
 
 static int launch_conv(const ConvArgs& a, hipStream_t st) {
+    if ((int64_t)(a.T > a.tc ? a.T : a.tc) * a.H * a.W > 0x7fffffffLL) return MG_ERR_SHAPE;   // 32-bit voxel index in the gather
     const int64_t tiles_m = (a.M + CV_BM - 1) / CV_BM;
     if (tiles_m > 0x7fffffffLL) return MG_ERR_SHAPE;
     int nb;

@@ -69,7 +69,7 @@ SIGNATURES = {
 _RESTYPE = {'mg_version': ctypes.c_char_p, 'mg_vae_attn_workspace_floats': ctypes.c_int64, 'mg_attn_set_lazy_rescale': None, 'mg_attn_set_variant': None,
             'mg_gemm_set_variant': None, 'mg_attn_debug_profile': None, 'mg_attn_w64_profile': None,
             'mg_attn_w64_debug': None, 'mg_gemm_debug_profile': None, 'mg_gemm5_debug_profile': None}
-DEFAULT_GEMM_VARIANT = 5   # must match g_gemm_variant in csrc/gemm_bf16.hip
+DEFAULT_GEMM_VARIANT = 0   # must match g_gemm_variant in csrc/gemm_bf16.hip (0 = by shape and epilogue)
 
 ERRORS = {-1: 'MG_ERR_ARG (null pointer / bad enum)', -2: 'MG_ERR_SHAPE (unsupported shape or alignment)',
           -3: 'MG_ERR_LAUNCH (kernel launch failed)', -4: 'MG_ERR_UNAVAILABLE (librccl could not be bound)',

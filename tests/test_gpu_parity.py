@@ -133,14 +133,14 @@ def test_gemm_tile_variants_agree(dev, M, N, K):
     b = W.randn((N,), 18).to(dev)
     outs = []
     try:
-        for v in (1, 2, 5, 6):
+        for v in (0, 1, 2, 5, 6):
             lib.load().mg_gemm_set_variant(v)
             o = torch.full((M + 1, N), -7.0, dtype=torch.float32, device=dev)      # guard row: no write past M
             ops.gemm(a, w, b, ops.BIAS_F32, o[:M])
             assert (o[M] == -7.0).all()
             outs.append(o[:M].clone())
     finally:
-        lib.load().mg_gemm_set_variant(5)
+        lib.load().mg_gemm_set_variant(lib.DEFAULT_GEMM_VARIANT)
     assert all(torch.equal(outs[0], o) for o in outs[1:])
 
 

@@ -70,15 +70,25 @@ def analyse(d, out=None):
         return tot
     c_tot = sum(e - s for s, e, _ in comm)
     c_ov = overlap([(s, e) for s, e, _ in comm])
-    lines = ['# tools/sp_overlap_trace.py: rocprofv3 --kernel-trace of the pipelined Ulysses exchange, backend nccl (RCCL), 1 rank, 4 head groups',
+    label = os.environ.get('SP_TRACE_LABEL', 'default')
+    lines = [f'# tools/sp_overlap_trace.py [{label}]: rocprofv3 --kernel-trace of the pipelined Ulysses exchange, backend nccl (RCCL), 1 rank, 4 head groups',
              f'attention kernels          : n={len(attn)} total_us={sum(b - a for a, b in attn) / 1e3:.1f}',
              f'RCCL kernels (all-to-all)  : n={len(comm)} total_us={c_tot / 1e3:.1f}  names={sorted({n.split("(")[0][:50] for _, _, n in comm})}',
              f'  of which UNDER attention : {c_ov / 1e3:.1f} us = {100.0 * c_ov / max(c_tot, 1):.1f} % of the RCCL kernel time',
              f'pack / unpack kernels      : n={len(pack)} total_us={sum(b - a for a, b in pack) / 1e3:.1f}',
              f'streams seen               : {sorted({st for *_, st in rows})}']
+    # a slice of the timeline (one layer of the last forward) for the record
+    rows.sort(key=lambda r: r[1])
+    last_attn = [i for i, r in enumerate(rows) if 'attn_hd128' in r[0]]
+    if last_attn:
+        i0 = max(0, last_attn[-9] - 6) if len(last_attn) >= 9 else 0
+        t0 = rows[i0][1]
+        lines.append('timeline slice (us from the first row; stream; duration us; kernel):')
+        for n, s_, e_, st in rows[i0:i0 + 34]:
+            lines.append(f'  {(s_ - t0) / 1e3:9.1f}  st={st:>3s}  {(e_ - s_) / 1e3:7.1f}  {n.split("(")[0][:60]}')
     text = '\n'.join(lines) + '\n'
     if out:
-        open(out, 'w').write(text)
+        open(out, 'a').write(text)
     print(text)
 
 
