@@ -25,6 +25,11 @@ import os
 import sys
 import time
 
+# HIP maps streams onto 4 hardware queues by default; the compute stream, the exchange stream and RCCL's own stream then
+# alias and the exchange of one head group serialises with the attention of the next (profiles/r02d_sp_overlap.txt:
+# 0 % overlap with 4 queues, 38-44 % of the RCCL kernel time under attention with 8).  Must be set before HIP initialises.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, 'moviigen1.1_amd'), os.path.join(ROOT, 'tests', 'golden')):
     if p not in sys.path:

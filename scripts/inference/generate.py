@@ -20,8 +20,10 @@ import random
 import sys
 from datetime import datetime
 
-import torch
-import torch.distributed as dist
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')   # before HIP initialises: see moviigen1.1_amd/wan/__init__.py
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, 'moviigen1.1_amd'))

@@ -28,6 +28,7 @@ from wan.distributed.xdit_context_parallel import enable_sequence_parallel  # no
 backend = os.environ.get('MOVIIGEN_TEST_BACKEND', 'gloo')
 local = int(os.environ.get('LOCAL_RANK', '0')) if backend == 'nccl' else 0
 os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 torch.cuda.set_device(local)
 dev = torch.device(f'cuda:{local}')
 if backend == 'nccl':
