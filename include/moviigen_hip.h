@@ -346,7 +346,6 @@ void mg_attn_w64_profile(unsigned long long* dev_buf);     /* w64 attention: 4 w
 void mg_attn_w64_debug(int flags);                         /* bit 0: keep the pipelined result of flagged blocks (no exact pass) */
 void mg_gemm_debug_profile(unsigned long long* dev_buf);   /* GEMM variants 1/2: 8 waves x {wait+barrier, stage issue, MFMA, k-tiles} */
 void mg_gemm5_debug_profile(unsigned long long* dev_buf);
-void mg_vae_set_conv_variant(int variant);                 /* 2 (default) = 256-voxel tile, one wave per SIMD, where it fits; 1 = the 128-voxel tile everywhere */  /* GEMM variant 5: 4 waves x the same four counters */
 
 #ifdef __cplusplus
 }

@@ -61,7 +61,6 @@ SIGNATURES = {
     'mg_attn_w64_debug': [c_int],
     'mg_gemm_debug_profile': [c_vp],
     'mg_gemm5_debug_profile': [c_vp],
-    'mg_vae_set_conv_variant': [c_int],
     'mg_image_to_u8': [c_vp, c_int, c_int, c_f32, c_f32, c_vp, c_vp],
     'mg_sp_pack_qkv_bf16': [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_int, c_vp, c_vp],
     'mg_sp_copy_blocks_bf16': [c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_int, c_i64, c_int, c_vp],
@@ -69,8 +68,7 @@ SIGNATURES = {
 }
 _RESTYPE = {'mg_version': ctypes.c_char_p, 'mg_vae_attn_workspace_floats': ctypes.c_int64, 'mg_attn_set_lazy_rescale': None, 'mg_attn_set_variant': None,
             'mg_gemm_set_variant': None, 'mg_attn_debug_profile': None, 'mg_attn_w64_profile': None,
-            'mg_attn_w64_debug': None, 'mg_gemm_debug_profile': None, 'mg_gemm5_debug_profile': None,
-            'mg_vae_set_conv_variant': None}
+            'mg_attn_w64_debug': None, 'mg_gemm_debug_profile': None, 'mg_gemm5_debug_profile': None}
 DEFAULT_GEMM_VARIANT = 0   # must match g_gemm_variant in csrc/gemm_bf16.hip (0 = by shape and epilogue)
 
 ERRORS = {-1: 'MG_ERR_ARG (null pointer / bad enum)', -2: 'MG_ERR_SHAPE (unsupported shape or alignment)',

@@ -49,4 +49,3 @@ def _reset_kernel_selection(request):
         h.mg_gemm_set_variant(lib.DEFAULT_GEMM_VARIANT)
         h.mg_attn_set_lazy_rescale(1)
         h.mg_attn_w64_debug(0)
-        h.mg_vae_set_conv_variant(2)

@@ -682,12 +682,12 @@ def test_fullsize_vae_conv_config5(dev, cin, cout, H, W, up2, kt):
 
 
 @pytest.mark.parametrize('cin,cout,T,H,W,tc,up2', [(96, 96, 2, 40, 72, 2, False), (32, 192, 1, 33, 47, 0, False), (64, 128, 3, 24, 40, 1, False),
-                                                  (192, 96, 2, 20, 36, 0, True), (16, 384, 1, 40, 64, 0, False)])
-def test_vae_conv_kernels_agree(dev, cin, cout, T, H, W, tc, up2):
-    """the 128-voxel kernel (two waves per SIMD) and the 256-voxel kernel (one wave per SIMD, interleaved staging) walk the
-    chunks in the same order: identical bits; and both match an fp64 evaluation on sampled voxels (ragged M, Cin < 32,
-    cache of 0 / 1 / 2 frames, the folded nearest-2x)."""
-    from wan.backend import lib, ops
+                                                  (192, 96, 2, 20, 36, 0, True), (16, 384, 1, 40, 64, 0, False), (40, 3, 2, 9, 11, 2, False)])
+def test_vae_conv_shapes(dev, cin, cout, T, H, W, tc, up2):
+    """the implicit-GEMM convolution with per-tap row pointers and the zero page for padding taps, on sampled voxels vs
+    an fp64 evaluation: ragged M, Cin < 32 and Cin % 32 != 0 (zero-weight tail of a chunk), cache of 0 / 1 / 2 frames,
+    the folded nearest-2x, Cout = 3 (head), bias + residual epilogue."""
+    from wan.backend import ops
     gen = torch.Generator(device=dev).manual_seed(cin * 7 + cout)
     kt = 1 if up2 else 3
     x = torch.randn(T, H, W, cin, device=dev, generator=gen)
@@ -696,16 +696,12 @@ def test_vae_conv_kernels_agree(dev, cin, cout, T, H, W, tc, up2):
     b = torch.randn(cout, device=dev, generator=gen)
     Ho, Wo = (2 * H, 2 * W) if up2 else (H, W)
     res = torch.randn(T, Ho, Wo, cout, device=dev, generator=gen)
-    outs = []
-    for variant in (1, 2):
-        lib.load().mg_vae_set_conv_variant(variant)
-        out = torch.empty(T, Ho, Wo, cout, device=dev)
-        ops.vae_conv(x, w, b, out, kt, 3, 3, cache=cache, up2=up2, residual=res)
-        outs.append(out)
-    assert torch.equal(outs[0], outs[1])
+    out = torch.full((T, Ho, Wo, cout), float('nan'), device=dev)
+    ops.vae_conv(x, w, b, out, kt, 3, 3, cache=cache, up2=up2, residual=res)
+    assert torch.isfinite(out).all().item()                       # every output element written, nothing read from a NaN
     pts = [(0, 0, 0), (T - 1, Ho - 1, Wo - 1), (0, Ho - 1, 0), (T - 1, 0, Wo - 1), (T // 2, Ho // 2, Wo // 2), (0, 1, Wo - 2)]
     ref = _conv_ref_f64(x, cache, w, b, pts, up2) + torch.stack([res[t, y, xx] for (t, y, xx) in pts]).double().cpu()
-    got = torch.stack([outs[1][t, y, xx] for (t, y, xx) in pts]).double().cpu()
+    got = torch.stack([out[t, y, xx] for (t, y, xx) in pts]).double().cpu()
     assert ((got - ref).abs().max() / ref.abs().max()).item() < 1e-5
 
 

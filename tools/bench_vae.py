@@ -18,13 +18,10 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--size', default='1920x832')
 ap.add_argument('--frames', type=int, default=81)
 ap.add_argument('--chunk', type=int, default=1, help='latent frames per decoder chunk after the first')
-ap.add_argument('--conv-variant', type=int, default=2, help='2 = 256-voxel tile, one wave per SIMD (default); 1 = 128-voxel tile')
 args = ap.parse_args()
 Wd, Hd = (int(v) for v in args.size.split('x'))
 T = (args.frames - 1) // 4 + 1
 dev = torch.device('cuda:0')
-from wan.backend import lib  # noqa: E402
-lib.load().mg_vae_set_conv_variant(args.conv_variant)
 vae = wan.modules.WanVAE(state_dict=W.make_vae_params(96, 1), device=dev)
 z = torch.randn(16, T, Hd // 8, Wd // 8, generator=torch.Generator().manual_seed(7)).to(dev)
 chunks = [1] + [args.chunk] * ((T - 1) // args.chunk) + ([(T - 1) % args.chunk] if (T - 1) % args.chunk else [])
@@ -35,6 +32,6 @@ torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 # conv FLOPs of the decoder at this size (1116.5 TF at 1920x832x81, scales with voxels)
 flops = 1116.5e12 * (Wd * Hd * args.frames) / (1920 * 832 * 81)
-print(json.dumps({'metric': 'vae_decode_sec', 'value': dt, 'conv_variant': args.conv_variant, 'size': args.size, 'frames': args.frames, 'chunks': chunks[:3],
+print(json.dumps({'metric': 'vae_decode_sec', 'value': dt, 'size': args.size, 'frames': args.frames, 'chunks': chunks[:3],
                   'tflops_fp32': flops / dt / 1e12, 'fp32_mfma_peak_tflops': 157.3, 'frac': flops / dt / 157.3e12,
                   'finite': bool(torch.isfinite(video).all().item()), 'peak_mem_gb': torch.cuda.max_memory_allocated() / 2**30}))
