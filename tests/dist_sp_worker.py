@@ -33,6 +33,21 @@ out = m([lat], t=t, context=[ctx], seq_len=L)[0]
 # every op is row-local except attention, whose key order is unchanged: results are bit-identical
 assert torch.equal(out, single), (out - single).abs().max().item()
 print(f'SP_OK rank{rank}', flush=True)
+# the reference's stand-alone sequence-parallel attention operator (xdit_context_parallel.py:155-198), installed the
+# reference's way (text2video.py:97-100) and called directly on this rank's token shard
+import types  # noqa: E402
+from wan.distributed.xdit_context_parallel import usp_attn_forward  # noqa: E402
+sa = m.blocks[1].self_attn
+xfull = W.randn((1, L, cfg['dim']), 77).to(dev)
+grid_t, lens_t = torch.tensor([[2, 4, 8]]), torch.tensor([L])
+whole = type(sa).forward(sa, xfull, lens_t, grid_t, m.freqs)                     # unsharded operator
+sa.forward = types.MethodType(usp_attn_forward, sa)
+Lr = L // 2
+mine = sa.forward(xfull[:, rank * Lr:(rank + 1) * Lr].contiguous(), lens_t, grid_t, m.freqs)
+assert torch.equal(mine, whole[:, rank * Lr:(rank + 1) * Lr]), (mine.float() - whole[:, rank * Lr:(rank + 1) * Lr].float()).abs().max().item()
+out = m([lat], t=t, context=[ctx], seq_len=L)[0]                                  # installed operator: still the fused path
+assert torch.equal(out, single)
+print(f'SP_ATTN_OP_OK rank{rank}', flush=True)
 shard_model(m, device_id=0)
 assert m.blocks[1].ffn['0'].weight.numel() == 0
 for _ in range(2):

@@ -759,6 +759,7 @@ def test_sequence_parallel_two_ranks_one_gpu():
                         os.path.join(root, 'tests', 'dist_sp_worker.py')], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert 'SP_OK rank0' in r.stdout and 'SP_OK rank1' in r.stdout
+    assert 'SP_ATTN_OP_OK rank0' in r.stdout and 'SP_ATTN_OP_OK rank1' in r.stdout
     assert 'SP_FSDP_OK rank0' in r.stdout and 'SP_FSDP_OK rank1' in r.stdout
 
 
