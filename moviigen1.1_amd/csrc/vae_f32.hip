@@ -142,6 +142,8 @@ __global__ __launch_bounds__(CV_THREADS) void vae_conv_kernel(const ConvArgs a) 
     // offset ((dy - kh/2) W + (dx - kw/2)) ldx — ~10 VALU per row and tap instead of ~40.
     unsigned vmask[4];
     const float* fbc[4];
+    const float* zp[4];                    // what an invalid tap reads: the zero page — or, for rows past M (never stored), row 0 of x:
+                                            // the 1x1 GEMMs of the attention block index it with channel offsets far beyond the page
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         unsigned mk = 0;
@@ -155,6 +157,7 @@ __global__ __launch_bounds__(CV_THREADS) void vae_conv_kernel(const ConvArgs a) 
         }
         vmask[i] = mk;
         fbc[i] = a.x;
+        zp[i] = valid ? g_cv_zero_page : a.x;
     }
     auto tap_pointers = [&]() __attribute__((always_inline)) {
         if (!a.up2) {
@@ -171,7 +174,7 @@ __global__ __launch_bounds__(CV_THREADS) void vae_conv_kernel(const ConvArgs a) 
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const unsigned ok = (vmask[i] >> ld_dt) & (vmask[i] >> (3 + ld_dy)) & (vmask[i] >> (6 + ld_dx)) & 1u;
-                pa[i] = ok ? fbc[i] + off : g_cv_zero_page;
+                pa[i] = ok ? fbc[i] + off : zp[i];
             }
             return;
         }
@@ -184,7 +187,7 @@ __global__ __launch_bounds__(CV_THREADS) void vae_conv_kernel(const ConvArgs a) 
             xx = min(max(xx, 0), a.Wo - 1) >> 1;
             const int tt = max(ti >= 0 ? ti : a.tc + ti, 0);          // (ti <= vt < T always: the taps only reach back in time)
             const int vox = (tt * a.H + yy) * a.W + xx;               // < 2^31 voxels per launch (checked on the host)
-            pa[i] = ok ? (ti >= 0 ? a.x : base_neg) + (int64_t)vox * a.ldx : g_cv_zero_page;
+            pa[i] = ok ? (ti >= 0 ? a.x : base_neg) + (int64_t)vox * a.ldx : zp[i];
         }
     };
     auto load_chunk = [&]() __attribute__((always_inline)) {

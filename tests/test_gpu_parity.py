@@ -455,14 +455,17 @@ def test_vae_modules_vs_oracle(dev, golden):
 # ------------------------------------------------------------------------------------------------
 # BASELINE.json configs[0] end to end through WanT2V.generate
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('L,C', [(3000, 32), (5001, 96), (700, 384)])
+@pytest.mark.parametrize('L,C', [(3000, 32), (5001, 96), (700, 384), (14400, 384)])
 def test_vae_attention_query_blocks(dev, L, C):
     """AttentionBlock arithmetic (vae.py:247-256) with more tokens than one 2048-row query block of the score
-    workspace (and a ragged last block): fp32 single-head softmax attention vs an fp64 evaluation."""
+    workspace (and a ragged last block): fp32 single-head softmax attention vs an fp64 evaluation.  (14 400, 384) is the
+    1280x720 decode's shape: its last block has 64 rows, so half of a 128-row tile lies past M while the channel offset
+    runs to 14 400 floats — those rows must not be pointed at the 4 KB zero page.)"""
     from wan.backend import ops
     gen = torch.Generator(device=dev).manual_seed(L)
-    qkv = torch.randn(2, L, 3 * C, device=dev, generator=gen)
-    out = torch.empty(2, L, C, device=dev)
+    frames = 1 if L > 10000 else 2
+    qkv = torch.randn(frames, L, 3 * C, device=dev, generator=gen)
+    out = torch.empty(frames, L, C, device=dev)
     ws = torch.empty(ops.vae_attn_workspace_floats(L, C), device=dev)
     assert ws.numel() <= (2048 + C) * (L + 3)
     ops.vae_attn(qkv, out, ws)
