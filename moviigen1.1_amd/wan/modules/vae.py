@@ -14,6 +14,7 @@ kernels as well.  The chunked decode with its 2-frame feature cache follows the 
 protocol (vae.py:101-141,202-220,423-472,544-568) slot for slot.
 """
 import logging
+import os
 
 import torch
 
@@ -188,7 +189,13 @@ class WanVAE_:
         x = ops.vae_latent_in(z, self.mean, self.inv_std, self._new(T, H, W, C))
         x = self._conv('conv2', x)
         if chunks is None:
-            chunks = [1] * T                     # the reference's chunking (vae.py:555-566)
+            # The reference decodes ONE latent frame per decoder call (vae.py:555-566) to bound its peak memory (2.45 GB
+            # per activation at 832x1920); the cache protocol makes any chunking of frames 1.. give the same values
+            # (tests: chunked == unchunked).  With 288 GB of HBM the engine decodes 4 latent frames
+            # per call: the low-resolution stages then launch enough tiles to fill 256 CUs (9.77 vs 10.16 s at
+            # 1920x832, peak 45 GB).  MOVIIGEN_VAE_CHUNK=1 restores the reference's chunking.
+            n = max(1, int(os.environ.get('MOVIIGEN_VAE_CHUNK', '4')))
+            chunks = [1] + [n] * ((T - 1) // n) + ([(T - 1) % n] if (T - 1) % n else [])
         assert sum(chunks) == T and chunks[0] == 1
         cache = [None] * (self.n_slots + 8)
         video = self._new(3, 1 + 4 * (T - 1), 8 * H, 8 * W)

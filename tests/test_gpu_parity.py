@@ -429,9 +429,11 @@ def test_vae_decode_vs_reference(dev, golden, dim, t):
     assert out.dtype == torch.float32 and tuple(out.shape) == g['video'].shape
     assert out.min() >= -1 and out.max() <= 1
     assert scale_err(out, g['video']) < 1e-4
-    if t >= 3:   # chunking freedom
-        out2 = vae.model.decode(T(g['z']).to(dev), chunks=[1, t - 1])
+    if t >= 3:   # chunking freedom: the default (4 latent frames per call), the reference's
+        out2 = vae.model.decode(T(g['z']).to(dev), chunks=[1, t - 1])      # one-frame chunks and one big chunk agree
         assert scale_err(out2, g['video']) < 1e-4
+        out1 = vae.model.decode(T(g['z']).to(dev), chunks=[1] * t)
+        assert scale_err(out1, g['video']) < 1e-4 and torch.equal(out1, out2) and torch.equal(out1, out)
 
 
 def test_vae_modules_vs_oracle(dev, golden):
