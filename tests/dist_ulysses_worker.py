@@ -52,6 +52,28 @@ c, u = cp.exchange(torch.full((2, 3), float(rank + 1)))
 assert torch.equal(c, torch.full((2, 3), 1.0)) and torch.equal(u, torch.full((2, 3), 2.0))
 print(f'CFGP_HOST_OK rank{rank}', flush=True)
 
+# ---- training-side sequence-parallel state (scripts/train/model/model_seq.py: FastVideo's nccl_info) ----------------
+import importlib.util  # noqa: E402
+spec = importlib.util.spec_from_file_location('model_seq', os.path.join(ROOT, 'scripts', 'train', 'model', 'model_seq.py'))
+ms = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(ms)
+assert not ms.get_sequence_parallel_state() and ms.nccl_info.sp_size == 1
+ms.initialize_sequence_parallel_state(P)
+assert ms.get_sequence_parallel_state() and ms.nccl_info.sp_size == P and ms.nccl_info.rank_within_group == rank
+assert dist.get_world_size(ms.nccl_info.group) == P and ms.nccl_info.group_id == 0
+msm = ms.WanModel(**dict(W.TINY_DIT, num_layers=1))
+msm._configure()
+assert msm.sp_size == P and msm.sp_rank == rank and msm.sp_mask_padded_keys and msm.cross_attn_head_sharded
+ms.initialize_sequence_parallel_state(1)
+msm._configure()
+assert msm.sp_size == 1 and not ms.get_sequence_parallel_state()
+print(f'TRAIN_SP_STATE_OK rank{rank}', flush=True)
+
+# ---- pipelined exchange: head groups ---------------------------------------------------------------------------
+assert ulysses.split_heads(5, 5) == [(0, 1), (1, 1), (2, 1), (3, 1), (4, 1)]
+assert ulysses.split_heads(10, 4) == [(0, 3), (3, 3), (6, 2), (8, 2)] and ulysses.split_heads(3, 8) == [(0, 1), (1, 1), (2, 1)]
+assert ulysses.split_heads(20, 1) == [(0, 20)]
+
 # ---- block-sharded weights: every rank keeps 1/P, fetch(i) reassembles block i exactly -------------
 cfg = dict(W.TINY_DIT, num_layers=3)
 Pm = W.make_dit_params(cfg, 0)

@@ -158,6 +158,7 @@ def test_ulysses_gloo_world2():
     assert 'ULYSSES_OK rank0' in r.stdout and 'ULYSSES_OK rank1' in r.stdout
     assert 'SHARDS_OK rank0' in r.stdout and 'SHARDS_OK rank1' in r.stdout
     assert 'CFGP_HOST_OK rank0' in r.stdout and 'CFGP_HOST_OK rank1' in r.stdout
+    assert 'TRAIN_SP_STATE_OK rank0' in r.stdout and 'TRAIN_SP_STATE_OK rank1' in r.stdout
 
 
 def test_vae_stage_partition():
