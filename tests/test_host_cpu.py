@@ -250,3 +250,22 @@ def test_tokenizer_ftfy_defaults_restated():
             ('é', 'é')]
     for text, want in rows:
         assert tk.clean_text(text, 'whitespace') == want, ascii(text)
+
+
+def test_bench_flop_formulas():
+    """bench.py's closed forms reproduce SURVEY.md 8(d): DiT FLOPs per forward at the three video sizes and the VAE decode
+    FLOPs at 1920x832x81 / 1280x720x81 (the numbers `roofline.achieved` and `vae_decode.tflops_fp32` are computed from)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(ROOT, 'bench.py'))
+    b = importlib.util.module_from_spec(spec)
+    argv, sys.argv = sys.argv, ['bench.py']
+    try:
+        spec.loader.exec_module(b)
+    finally:
+        sys.argv = argv
+    for L, pf in ((75600, 6.5234), (131040, 17.2571), (166320, 26.7095)):
+        assert abs(b.flops_per_forward(L, b.MODEL_14B) / 1e15 - pf) < 1e-3
+    tot, attn = b.vae_decode_flops(21, 104, 240)
+    assert abs(tot / 1e12 - 1116.5) < 0.1 and abs(attn / 1e12 - 20.1) < 0.05
+    assert abs(b.vae_decode_flops(21, 90, 160)[0] / 1e12 - 639.2) < 0.1
+    assert b.WORKLOADS['1080p'][:3] == (1920, 832, 81)
