@@ -104,6 +104,7 @@ __global__ __launch_bounds__(NT) void rmsnorm_rope_kernel(
     int dim, const float* __restrict__ weight, float eps, int head_dim, const float2* __restrict__ rope_cs,
     int F, int H, int W, int64_t pos0) {
     __shared__ float red[NT / 64];
+    __shared__ float2 cs_row[128];          // the token's (cos, sin) pairs, identical for every head: staged once per row
     const int nc = dim >> 3;
     const int c = head_dim >> 1, c1 = c / 3, c0 = c - 2 * c1;
     const float2* tab_f = rope_cs;
@@ -126,16 +127,17 @@ __global__ __launch_bounds__(NT) void rmsnorm_rope_kernel(
                 }
             }
         }
-        const float r = rsqrtf(block_sum<NT>(ss, red) / (float)dim + eps);
         const int64_t tok = pos0 + row;
         const bool do_rope = rope_cs != nullptr && tok < grid_tokens;
-        int pf = 0, ph = 0, pw = 0;
-        if (do_rope) {
-            pf = (int)(tok / ((int64_t)H * W));
+        if (do_rope && (int)threadIdx.x < c) {       // c <= 128 pairs: [c0 temporal | c1 height | c1 width] of this token
+            const int pf = (int)(tok / ((int64_t)H * W));
             const int rem = (int)(tok - (int64_t)pf * H * W);
-            ph = rem / W;
-            pw = rem - ph * W;
+            const int ph = rem / W, pw = rem - ph * W;
+            const int p = threadIdx.x;
+            cs_row[p] = p < c0 ? tab_f[(int64_t)pf * c0 + p]
+                               : (p < c0 + c1 ? tab_h[(int64_t)ph * c1 + (p - c0)] : tab_w[(int64_t)pw * c1 + (p - c0 - c1)]);
         }
+        const float r = rsqrtf(block_sum<NT>(ss, red) / (float)dim + eps);    // (its barriers also publish cs_row)
 #pragma unroll
         for (int i = 0; i < MAXC; ++i) {
             const int ch = threadIdx.x + i * NT;
@@ -148,11 +150,7 @@ __global__ __launch_bounds__(NT) void rmsnorm_rope_kernel(
                     const int p0 = (col % head_dim) >> 1;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const int p = p0 + j;
-                        float2 cs;
-                        if (p < c0) cs = tab_f[(int64_t)pf * c0 + p];
-                        else if (p < c0 + c1) cs = tab_h[(int64_t)ph * c1 + (p - c0)];
-                        else cs = tab_w[(int64_t)pw * c1 + (p - c0 - c1)];
+                        const float2 cs = cs_row[p0 + j];
                         const float a = y[2 * j], b = y[2 * j + 1];
                         y[2 * j] = a * cs.x - b * cs.y;
                         y[2 * j + 1] = a * cs.y + b * cs.x;
@@ -166,6 +164,7 @@ __global__ __launch_bounds__(NT) void rmsnorm_rope_kernel(
                 ((u32x4_t*)(out + row * ldo))[ch] = o;
             }
         }
+        if (row + gridDim.x < rows) __syncthreads();     // cs_row is rewritten by the next row of this workgroup
     }
 }
 
@@ -178,7 +177,7 @@ extern "C" int mg_rmsnorm_rope_bf16(const uint16_t* x, int64_t ldx, uint16_t* ou
     if (dim <= 0 || (dim & 7) || dim > 8192 || (ldx & 7) || (ldo & 7) || head_dim <= 0 ||
         (head_dim & 7) || dim % head_dim)
         return MG_ERR_SHAPE;
-    if (rope_cs && (F <= 0 || H <= 0 || W <= 0)) return MG_ERR_SHAPE;
+    if (rope_cs && (F <= 0 || H <= 0 || W <= 0 || head_dim > 256)) return MG_ERR_SHAPE;
     if (rows <= 0) return MG_OK;
     hipStream_t st = (hipStream_t)stream;
     const int grid = (int)(rows < 65536 * 4 ? rows : 65536 * 4);
