@@ -7,8 +7,13 @@ two WanModel forwards (cond / uncond), the CFG combine and one UniPC scheduler s
 synthetic data of the configuration BASELINE.json's `metric` is quoted on: 14B T2V,
 1920x832x81f (latent [16,21,104,240], L = 131 040 tokens) — it fits one MI355X, so N=1 runs
 it unsharded (`--workload 720p` = BASELINE configs[1], 1280x720x81f, L = 75 600).
-N>1 (launched by torch.distributed.run, one rank per GPU): the SAME video with Ulysses
-sequence parallelism over RCCL -> strong scaling.
+N>1 (one rank per GPU): the SAME video sharded over the ranks — cond / uncond halves x Ulysses sequence parallelism
+over RCCL (`--no-cfg-parallel`: Ulysses over all N ranks) -> strong scaling.  Launched either by torch.distributed.run
+(the driver's form; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment) or PLAINLY — `python bench.py
+--gpus N` without WORLD_SIZE re-executes itself under torch.distributed.run on 127.0.0.1 (reference launch contract:
+scripts/inference/generate.py:190-229, one process per GPU + init_process_group("nccl")).  The N > 1 line additionally
+reports what RCCL saw: `rccl_ranks`, the device of every rank, the transport and the measured overlap (fraction of the
+exchange time the compute stream did NOT wait for, from events on both streams).
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (self-attention, 82 % of
 the FLOPs at this size): algorithmic FLOPs per launch / mean launch duration, measured live with
@@ -84,12 +89,15 @@ def vae_decode_flops(T, h, w):
 
 
 def cpu_baseline(L_step, lat_shape):
-    """The oracle (CPU restatement, fp32, all usable host cores) on the bounded slices SURVEY.md §8(d) names:
+    """The oracle (CPU restatement, fp32, all usable host cores) on the bounded slices SURVEY.md §8(d) names, each leg
+    timed as the BEST of several runs (a single run swings +-50 % from box to box):
       * ONE 14B-width WanAttentionBlock (d=5120, 40 heads, ffn 13824, 512 text keys) at L = 4 096 (grid 4x32x32),
         and its self-attention alone on the same shapes, so the step is extrapolated in two parts:
         t_step = F_linear(step) / r_linear + F_attention(step) / r_attention  (FLOP formula of SURVEY §8(d));
+      * the full 40-layer model at L = 1 024 (grid 4x16x16; the 40 blocks share one set of weights: same arithmetic,
+        0.7 instead of 28 GB of host memory) — a whole-forward cross-check of the extrapolation rule;
       * BASELINE configs[0] in full (2-layer dim-128 DiT, latent [16,1,8,8], 2 UniPC steps with CFG);
-      * the VAE decode of z[16,5,32,32] -> [3,17,256,256], extrapolated to the workload's latent by FLOPs."""
+      * the VAE decode of z[16,3,32,32] -> [3,9,256,256], extrapolated to the workload's latent by FLOPs."""
     import weights as W
     from oracle import dit, schedulers as osch, vae as ovae
     torch.set_num_threads(_usable_cores())
@@ -104,15 +112,18 @@ def cpu_baseline(L_step, lat_shape):
     ctx = torch.randn(512, d, generator=g)
     tabs = dit.rope_table(128)
 
-    def timed(fn, reps):
-        fn()
-        t0 = time.time()
-        for _ in range(reps):
+    def best(fn, reps, warm=True):
+        if warm:
             fn()
-        return (time.time() - t0) / reps
-    t_blk = timed(lambda: dit.block(P, 'blocks.0.', x, e0, L, grid, tabs, ctx, N, 1e-6, False, False), 1)
+        ts_ = []
+        for _ in range(reps):
+            t0 = time.time()
+            fn()
+            ts_.append(time.time() - t0)
+        return min(ts_)
+    t_blk = best(lambda: dit.block(P, 'blocks.0.', x, e0, L, grid, tabs, ctx, N, 1e-6, False, False), 2)
     q = torch.randn(L, N, 128, generator=g)
-    t_att = timed(lambda: dit.attention(q, q, q, L, False), 2)
+    t_att = best(lambda: dit.attention(q, q, q, L, False), 3)
     F_att = 4 * L * L * d
     F_lin = 12 * L * d * d + 4 * 512 * d * d + 4 * L * d * f + 4 * L * 512 * d
     r_att, r_lin = F_att / t_att, F_lin / max(t_blk - t_att, 1e-9)
@@ -121,35 +132,64 @@ def cpu_baseline(L_step, lat_shape):
     F_lin_step = 2 * fl_fwd - F_att_step
     t_step = F_lin_step / r_lin + F_att_step / r_att
 
+    # the full depth at L = 1024: 40 blocks over one block's weights
+    class Shared(dict):
+        def __missing__(self, key):
+            if key.startswith('blocks.'):
+                return self['blocks.0.' + key.split('.', 2)[2]]
+            raise KeyError(key)
+    cfg40 = dict(cfg, num_layers=40, text_dim=4096)
+    P40 = Shared(P)
+    for k, s_ in W.dit_param_shapes(dict(cfg40, num_layers=0)).items():
+        if k not in P40:
+            P40[k] = torch.randn(s_, generator=g) * 0.02
+    lat40 = torch.randn(16, 4, 32, 32, generator=g)
+    ctx40 = torch.randn(512, 4096, generator=g)
+    t_l1024 = best(lambda: dit.dit_forward(P40, cfg40, lat40, torch.tensor([500]), ctx40, 1024), 1, warm=False)
+    fl_l1024 = flops_per_forward(1024, MODEL_14B)
+    pred_l1024 = (fl_l1024 - 40 * 4 * 1024 * 1024 * d) / r_lin + 40 * 4 * 1024 * 1024 * d / r_att
+
     # BASELINE configs[0], in full
     c0 = W.TINY_DIT
     P0 = W.make_dit_params(c0, 0)
     lat0, ctx0, ctxn0 = W.randn((16, 1, 8, 8), 1), W.randn((11, c0['text_dim']), 2), W.randn((5, c0['text_dim']), 3)
-    t0 = time.time()
-    osch.sample_loop(lambda lat, t, c: dit.dit_forward(P0, c0, lat, t, c, 16), lat0, ctx0, ctxn0, 2, 5.0, 5.0, 'unipc')
-    t_cfg0 = time.time() - t0
+    t_cfg0 = best(lambda: osch.sample_loop(lambda lat, t, c: dit.dit_forward(P0, c0, lat, t, c, 16), lat0, ctx0, ctxn0, 2, 5.0,
+                                           5.0, 'unipc'), 3)
 
     # VAE slice
     Pv = W.make_vae_params(96, 1)
-    z = torch.randn(16, 5, 32, 32, generator=g)
-    t0 = time.time()
-    ovae.vae_decode(Pv, z)
-    t_vae = time.time() - t0
-    fv_slice = vae_decode_flops(5, 32, 32)[0]
+    z = torch.randn(16, 3, 32, 32, generator=g)
+    t_vae = best(lambda: ovae.vae_decode(Pv, z), 2, warm=False)
+    fv_slice = vae_decode_flops(3, 32, 32)[0]
     fv_full = vae_decode_flops(*lat_shape[1:])[0]
     return {'value': 1.0 / t_step, 'unit': 'steps/s', 'cores': torch.get_num_threads(), 'kind': 'port',
             'block_L4096_s': round(t_blk, 3), 'attention_L4096_s': round(t_att, 3),
             'gflops_linear': round(r_lin / 1e9, 1), 'gflops_attention': round(r_att / 1e9, 1),
             'sec_per_step_extrapolated': round(t_step, 1),
-            'config0_2steps_s': round(t_cfg0, 3),
+            'model40_L1024_forward_s': round(t_l1024, 2), 'model40_L1024_predicted_by_rule_s': round(pred_l1024, 2),
+            'model40_L1024_gflops': round(fl_l1024 / t_l1024 / 1e9, 1),
+            'config0_2steps_s': round(t_cfg0, 4),
             'vae': {'slice_s': round(t_vae, 2), 'gflops': round(fv_slice / t_vae / 1e9, 1),
                     'decode_s_extrapolated': round(fv_full / (fv_slice / t_vae), 1),
-                    'sample': 'oracle/vae.py vae_decode of z[16,5,32,32] -> [3,17,256,256] (dim-96 decoder), 1 run, '
+                    'sample': 'oracle/vae.py vae_decode of z[16,3,32,32] -> [3,9,256,256] (dim-96 decoder), best of 2 runs, '
                               'extrapolated to the workload latent by the decoder FLOP count'},
-            'sample': f'oracle/dit.py block (d=5120, 40 heads, ffn=13824, 512 text keys) at L=4096: {t_blk:.2f}s per run, '
-                      f'its self-attention alone {t_att:.2f}s; rule: t_step = F_linear/r_linear + F_attention/r_attention '
-                      f'with the step FLOPs of SURVEY 8(d) ({2 * fl_fwd / 1e15:.2f} PFLOP at L={L_step}); '
-                      f'configs[0] (2-layer dim-128 DiT, 2 UniPC steps, CFG) in full: {t_cfg0:.2f}s'}
+            'sample': f'oracle/dit.py block (d=5120, 40 heads, ffn=13824, 512 text keys) at L=4096: {t_blk:.2f}s (best of 2 after a warm-up), '
+                      f'its self-attention alone {t_att:.2f}s (best of 3); rule: t_step = F_linear/r_linear + F_attention/r_attention '
+                      f'with the step FLOPs of SURVEY 8(d) ({2 * fl_fwd / 1e15:.2f} PFLOP at L={L_step}); the full 40-layer model at '
+                      f'L=1024 (shared block weights): {t_l1024:.1f}s measured vs {pred_l1024:.1f}s by the rule; '
+                      f'configs[0] (2-layer dim-128 DiT, 2 UniPC steps, CFG) in full: {t_cfg0:.3f}s (best of 3)'}
+
+
+def launch_command(n, argv, port=None):
+    """the torch.distributed.run command line `python bench.py --gpus n ...` re-executes itself under when it is
+    started without WORLD_SIZE (one rank per GPU of this node, rendezvous on 127.0.0.1)."""
+    if port is None:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+            '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
 
 
 def main():
@@ -166,6 +206,16 @@ def main():
     ap.add_argument('--layers', type=int, default=None, help='debug only: fewer layers (marks the line invalid)')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher of N ranks (the driver's torchrun form skips this)
+        import subprocess
+        cmd = launch_command(args.gpus, sys.argv[1:])
+        if os.environ.get('MOVIIGEN_BENCH_DRYRUN'):
+            print(json.dumps({'launch': cmd}), flush=True)
+            return
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        sys.exit(subprocess.call(cmd, env=env))
+
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -176,6 +226,9 @@ def main():
         dist.init_process_group('gloo')
     elif world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        if torch.cuda.device_count() < world:
+            raise SystemExit(f'bench.py --gpus {world}: one rank per GPU over RCCL needs {world} visible GPUs, this node shows '
+                             f'{torch.cuda.device_count()} (MOVIIGEN_BENCH_BACKEND=gloo runs the code path on one GPU: not a measurement)')
         torch.cuda.set_device(local)
         dist.init_process_group('nccl', device_id=torch.device(f'cuda:{local}'))
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)'
@@ -223,15 +276,15 @@ def main():
     orig_attn = ops.attention_hd128
     recording = {'on': False}
 
-    def timed_attn(q, k, vt, out, lk, heads, scale):
+    def timed_attn(q, k, vt, out, lk, heads, scale, **kw):
         if recording['on'] and lk > 1024:
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            r = orig_attn(q, k, vt, out, lk, heads, scale)
+            r = orig_attn(q, k, vt, out, lk, heads, scale, **kw)
             b.record()
-            attn_events.append((a, b))
+            attn_events.append((a, b, heads))
             return r
-        return orig_attn(q, k, vt, out, lk, heads, scale)
+        return orig_attn(q, k, vt, out, lk, heads, scale, **kw)
     ops.attention_hd128 = timed_attn
 
     noise_pred = torch.empty_like(latent)
@@ -257,6 +310,9 @@ def main():
     for i in range(args.warmup):
         step(i)
     fence()
+    from wan.distributed.ulysses import HeadExchange
+    if world > 1:
+        HeadExchange.trace = []          # events around every collective / every wait of the compute stream on one
     recording['on'] = True
     t0 = time.perf_counter()
     for i in range(args.warmup, total):
@@ -264,10 +320,17 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     recording['on'] = False
+    overlap = rank_devices = None
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = tt.item()
+        overlap = HeadExchange.overlap_summary()
+        HeadExchange.trace = None
+        mine = {'rank': rank, 'device': f'cuda:{local}', 'name': torch.cuda.get_device_name(dev),
+                'uuid': str(getattr(torch.cuda.get_device_properties(dev), 'uuid', ''))}
+        rank_devices = [None] * world
+        dist.all_gather_object(rank_devices, mine)
     assert torch.isfinite(latent).all().item(), 'non-finite latent'
 
     # ---- the rest of sec/video (reference wan/text2video.py:228-261), measured in this same process after the timed
@@ -319,9 +382,9 @@ def main():
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
         fl_fwd = flops_per_forward(L, cfg)
-        attn_ms = sum(a.elapsed_time(b) for a, b in attn_events) / max(1, len(attn_events))
-        heads_loc = cfg['num_heads'] // sp
-        attn_flops = 4.0 * L * L * 128 * heads_loc
+        attn_ms = sum(a.elapsed_time(b) for a, b, _ in attn_events) / max(1, len(attn_events))
+        heads_launch = attn_events[0][2] if attn_events else cfg['num_heads'] // sp      # heads of ONE timed launch (a head group when sharded)
+        attn_flops = 4.0 * L * L * 128 * heads_launch
         ach = attn_flops / (attn_ms * 1e-3) / 1e12 if attn_events else None
         # the cross-attention K/V projections and the text embedding are per-prompt work cached outside the timed
         # region (WanModel._context): they are NOT counted in the executed-FLOP rate
@@ -341,7 +404,7 @@ def main():
                                             'process; T5 reported separately (SURVEY 8(d))'},
             'model_tflops_per_gpu': fl_step / (elapsed / args.steps) / world / 1e12,
             'mfma_frac_whole_step': fl_step / (elapsed / args.steps) / world / PEAK_BF16,
-            'roofline': {'kernel': 'attn_hd128_w64_kernel (self-attention, mg_attn_fwd_bf16_hd128)', 'bound': 'mfma',
+            'roofline': {'kernel': 'attn_hd128_m16_kernel (self-attention, mg_attn_fwd_bf16_hd128_prescaled)', 'bound': 'mfma',
                          'achieved': ach, 'peak': PEAK_BF16 / 1e12, 'unit': 'TFLOP/s',
                          'frac': (ach * 1e12 / PEAK_BF16) if ach else None, 'traffic': None,
                          'launches_timed': len(attn_events), 'ms_per_launch': attn_ms,
@@ -364,6 +427,22 @@ def main():
                     pmc = json.load(f)
                 line['roofline']['traffic'] = pmc.get('traffic_bytes_per_launch')
                 line['roofline']['traffic_unit'] = 'bytes/launch (FETCH_SIZE x2 + WRITE_SIZE, ' + os.path.basename(found[-1]) + ')'
+        if world > 1:
+            from wan.distributed import rccl_direct
+            gloo = os.environ.get('MOVIIGEN_BENCH_BACKEND') == 'gloo'
+            line['rccl_ranks'] = 0 if gloo else world
+            line['rank_devices'] = rank_devices
+            line['transport'] = ('gloo through host memory (test plumbing)' if gloo else
+                                 "C-ABI collectives on the library's RCCL communicator (mg_sp_all_to_all: grouped ncclSend/ncclRecv)"
+                                 if rccl_direct.enabled() else 'torch.distributed backend nccl (= RCCL): all_to_all_single on a comm stream')
+            if overlap and overlap['collectives']:
+                per = 1.0 / args.steps
+                line['overlap'] = {'exchange_ms_per_step': overlap['exchange_ms'] * per, 'exposed_ms_per_step': overlap['exposed_ms'] * per,
+                                   'hidden_frac': overlap['hidden_frac'], 'collectives_per_step': overlap['collectives'] * per,
+                                   'how': 'rank 0: timing events around every all-to-all on the comm stream (exchange) and around every '
+                                          'wait of the compute stream on the comm stream (exposed); hidden = 1 - exposed / exchange'}
+            else:
+                line['overlap'] = None      # no per-layer exchange in this layout (e.g. cfg2 on 2 ranks: one forward per rank)
         if os.environ.get('MOVIIGEN_BENCH_BACKEND') == 'gloo':
             line['invalid'] = 'gloo test transport on a shared GPU (code-path check, not a measurement)'
         if args.layers or args.workload == 'tiny':

@@ -61,17 +61,23 @@ int mg_ln_modulate(const float* x, int64_t ldx, int64_t rows, int dim, const flo
  *            [F][c0] ++ [H][c1] ++ [W][c1] with c = head_dim/2, c1 = c/3, c0 = c - 2*c1
  *   token index of row r is pos0 + r, decomposed (f,h,w) row-major over the F*H*W grid;
  *   rows with token index >= F*H*W are passed through un-rotated (padding, model.py:61).
+ *   out_scale: the fp32 result is multiplied by it before the (single) rounding to bf16; 1 = the reference value.
+ *            WanModel.forward passes softmax_scale*log2(e) for q, so that mg_attn_fwd_bf16_hd128_prescaled needs no
+ *            per-score multiply (flash_attn applies softmax_scale to the fp32 scores: same product, one rounding
+ *            either way, taken at a different point).
  * dim % 8 == 0, dim <= 8192, head_dim % 2 == 0, dim % head_dim == 0, ldx/ldo % 8 == 0. */
 int mg_rmsnorm_rope_bf16(const uint16_t* x, int64_t ldx, uint16_t* out, int64_t ldo,
                          int64_t rows, int dim, const float* weight, float eps, int head_dim,
-                         const float* rope_cs, int F, int H, int W, int64_t pos0, void* stream);
+                         const float* rope_cs, int F, int H, int W, int64_t pos0, float out_scale, void* stream);
 
 /* Pack K and/or V (row-major [L][>=heads*128], row strides ldk/ldv; either may be NULL) into the
- * per-64-key-tile operand layout of mg_attn_fwd_bf16_hd128, nt = ceil(L/64) tiles per head:
- *     kp[head][tile][c = d/8 (16)][r = key%64 (64)][8]
+ * per-64-key-tile operand layout of mg_attn_fwd_bf16_hd128*, nt = ceil(L/64) tiles per head:
+ *     kp[head][tile][c = d/8 (16)][row (64)][8]      key 32u + 8a + 4b + j of the tile sits in row 32u + 16b + 4a + j
  *     vp[head][tile][kc = (key%64)/8 (8)][d (128)][8 keys]
  * each tile = one contiguous 16 KiB block = the LDS image (pure LDS-DMA staging, conflict-free
- * ds_read_b128 with immediate offsets); keys >= L are zero.  kp/vp: heads*nt*8192 elements each,
+ * ds_read_b128 with immediate offsets); keys >= L are zero.  The K row order is the one the 16x16x32 attention kernel
+ * wants (its scores come out as the B operand of P.V without a shuffle); under mg_attn_set_variant(3) the rows are
+ * in natural order (row = key % 64) for the A/B partner kernel.  kp/vp: heads*nt*8192 elements each,
  * 16-byte aligned.  No reference counterpart (flash_attn stages K/V inside its kernel). */
 int mg_pack_kv_bf16(const uint16_t* k, int64_t ldk, const uint16_t* v, int64_t ldv, int64_t L,
                     int heads, int head_dim, uint16_t* kp, uint16_t* vp, void* stream);
@@ -126,6 +132,14 @@ int mg_attn_fwd_bf16_hd128(const uint16_t* q, int64_t ldq, const uint16_t* kp, c
 int mg_attn_fwd_bf16_hd128_lse(const uint16_t* q, int64_t ldq, const uint16_t* kp, const uint16_t* vp,
                                uint16_t* o, int64_t ldo, float* lse, int64_t Lq, int64_t Lk, int heads,
                                float scale, void* stream);
+
+/* Same operator for a q that ALREADY carries the factor scale*log2(e) (mg_rmsnorm_rope_bf16 with out_scale: the factor
+ * enters before q's one rounding to bf16, so nothing is rounded twice) — the form WanModel.forward uses.  With the
+ * default kernel a score then IS its base-2 exponent (no per-score multiply-add).  lse may be NULL; when given it is
+ * the natural-log log-sum-exp of the true scaled scores, as above. */
+int mg_attn_fwd_bf16_hd128_prescaled(const uint16_t* q, int64_t ldq, const uint16_t* kp, const uint16_t* vp,
+                                     uint16_t* o, int64_t ldo, float* lse, int64_t Lq, int64_t Lk, int heads,
+                                     void* stream);
 
 /* x[r][c] += float(y[r][c]) * gate[c]: the gated residual update of wan/modules/model.py:301-302,306,308-309 as a
  * stand-alone kernel (x fp32 [rows][dim] row stride ldx; y bf16 row stride ldy; gate fp32 [dim] or NULL = 1).
@@ -208,15 +222,12 @@ int mg_attn_fwd_bf16_generic(const uint16_t* q, int64_t ldq, const uint16_t* k, 
                              const uint16_t* v, int64_t ldv, uint16_t* o, int64_t ldo, int64_t Lq,
                              int64_t Lk, int heads, int head_dim, float scale, void* stream);
 
-/* Tuning knob: 1 (default) = defer the online-softmax rescale while no row maximum grew by more
- * than 2^8 since the last rescale (P <= 256 in bf16); 0 = rescale every tile. */
-void mg_attn_set_lazy_rescale(int on);
-/* Kernel behind mg_attn_fwd_bf16_hd128 (same math in all):
- * 0 = auto (default): 3 when Lk >= 512 (self- and cross-attention of the DiT), else 1;
- * 1 = two-level lock-step kernel, 8 waves x 32 queries, LDS fragment reads scheduled by hipcc;
- * 2 = same kernel with a hand-issued ds_read_b128 ring (8 deep, counted lgkmcnt);
- * 3 = "w64": 4 waves x 64 queries, one wave per SIMD, software-pipelined in 32-key units
- *     (csrc/attn_hd128_w64.hip).  Other values select 1. */
+/* Kernel behind mg_attn_fwd_bf16_hd128* and the matching K row order of mg_pack_kv_bf16 — a process-global
+ * MEASUREMENT / TEST switch (same math in both), not part of the drop-in contract and not thread-safe:
+ * 0 = "m16" (default): 4 waves x 64 queries, one wave per SIMD, v_mfma_f32_16x16x32_bf16, zero-reference softmax,
+ *     software-pipelined in 32-key units (csrc/attn_hd128_m16.hip);
+ * 3 = "w64": the round-2 kernel (32x32x16 MFMA, per-row softmax reference; csrc/attn_hd128_w64.hip).
+ * Other values select 0.  Pack and attend under the same setting. */
 void mg_attn_set_variant(int variant);
 
 /* ------------------------------------------------------------------------------------------
@@ -341,9 +352,9 @@ int mg_vae_time_interleave_f32(const float* x, int T, int64_t HW, int C, float* 
  * csrc/tools/selftest.cpp and tools/ to take s_memtime breakdowns of the hot loops and to force kernel
  * schedules for A/B measurements.  All are process-global switches; passing NULL / 0 restores the default.
  * ---------------------------------------------------------------------------------------- */
-void mg_attn_debug_profile(unsigned long long* dev_buf);   /* lock-step attention: 8 waves x {S^T, softmax, P.V, fence, tiles} cycles */
-void mg_attn_w64_profile(unsigned long long* dev_buf);     /* w64 attention: 4 waves x {fence, step A, step B, iterations} */
+void mg_attn_w64_profile(unsigned long long* dev_buf);     /* both attention kernels: 4 waves x {fence, step A, step B, iterations} */
 void mg_attn_w64_debug(int flags);                         /* bit 0: keep the pipelined result of flagged blocks (no exact pass) */
+void mg_attn_w64_flag_counter(unsigned* dev_counter);      /* both kernels: *dev_counter += query blocks redone by the exact pass */
 void mg_gemm_debug_profile(unsigned long long* dev_buf);   /* GEMM variants 1/2: 8 waves x {wait+barrier, stage issue, MFMA, k-tiles} */
 void mg_gemm5_debug_profile(unsigned long long* dev_buf);
 

@@ -1,0 +1,551 @@
+// Flash-style attention forward, head_dim 128 — schedule "m16": the one-wave-per-SIMD pipeline of attn_hd128_w64.hip
+// rebuilt on v_mfma_f32_16x16x32_bf16.
+//
+// Why the other MFMA shape (experiments/mfma_shape_probe.hip): on random data this kernel is limited by
+// the chip's POWER budget, not by issue cycles — cutting 11 % of the w64 kernel's cycles returned 4 % of throughput, the
+// rest went into a lower clock.  16x16x32 does the same FLOPs with 8x less accumulator traffic (4 instead of 16
+// registers read and written per instruction and lane): with an attention-like filler mix one wave per SIMD sustains
+// 1565 TFLOP/s on it against 1420 on 32x32x16 (2.07 vs 1.83 GHz).  Register budget, LDS traffic (a fragment still feeds
+// 64 queries), tile images, refill protocol and the software pipeline are those of w64; what changes is the tiling:
+//
+//   wave = 64 queries = 4 query blocks of 16; lane = (qi = lane & 15: the query inside a block, G = lane >> 4).
+//   S^T (16 keys x 16 queries) = K.Q^T: A = K fragment [16 key rows][32 d], B = Q^T [32 d][16 queries]; a 32-key unit
+//       = 2 key blocks (a, b) x 4 d chunks = 8 K fragments x 4 query blocks = 32 MFMAs.  Lane (qi, G) receives rows
+//       4G..4G+3 of each block; the K tile stores its rows PERMUTED (mg_pack_kv_bf16) so that these are keys
+//       8G..8G+3 (block a) and 8G+4..8G+7 (block b) of the unit and the 16 lanes of a read still touch 16 consecutive
+//       16-byte slots (no bank conflicts):  tile row 32u + 16*block + i  <->  key 32u + 8*(i>>2) + 4*block + (i&3).
+//   P (bf16) of a query block is then directly the B operand [32 keys][16 queries] of O^T = V^T.P^T: lane (qi, G)
+//       holds keys 8G..8G+7 = [a0 a1 a2 a3 b0 b1 b2 b3], and the A operand V^T [16 d rows][32 keys] is one 16-byte read
+//       of the V tile image (8 consecutive keys of one d): 8 V fragments (d blocks) x 4 query blocks = 32 MFMAs.
+//   O^T: lane (qi, G) holds d = 16*db + 4G + r of its query: four consecutive d per d block, 8-byte stores.
+//
+// Softmax: ZERO reference.  A common factor 2^-m per row cancels in O / l, so the running maximum of the textbook
+// online softmax only has to keep p representable — and P is bf16, O^T and l are fp32: p = 2^(s*c) with NO maximum,
+// no rescale and no branch in the hot loop; a final row sum outside [2^-60, 2^90] (or inf / NaN; l only grows, so one
+// test at the end covers every partial sum) flags the workgroup, which then redoes its block with the plain exact loop
+// (true running maximum).  With the DiT's RMS-normed q and k the scores are bounded by |q||k|/sqrt(d) and nothing flags.
+// SCALED = false (mg_attn_fwd_bf16_hd128_prescaled, what WanModel.forward uses): q already carries c = scale*log2(e)
+// (mg_rmsnorm_rope_bf16 out_scale: the factor enters before q's one rounding to bf16), a score IS its exponent and the
+// softmax costs exp + add + half a cvt_pk per score.  SCALED = true (any q, any scale): one v_mul more per score, q is
+// used as given (no second rounding).
+#include <type_traits>
+#include "common.h"
+#include "../../include/moviigen_hip.h"
+
+#define M16_THREADS 256
+#define M16_QB 256
+#define M16_TILE 16384
+#define M16_K(slot) ((slot) * M16_TILE)
+#define M16_V(slot) (3 * M16_TILE + (slot) * M16_TILE)
+
+typedef const __attribute__((address_space(1))) void* m16_gptr_t;
+typedef __attribute__((address_space(3))) void* m16_lptr_t;
+MG_DEV bf16x8_t m16_bf(u32x4_t v) { return __builtin_bit_cast(bf16x8_t, v); }
+// piece n of a wave's four consecutive 1 KiB pieces: the immediate offset advances the global AND the LDS address
+MG_DEV void m16_glds16_n(const void* g, void* l, int n) {
+    switch (n) {    // compile-time after unrolling; the builtin wants a literal
+        case 0: __builtin_amdgcn_global_load_lds((m16_gptr_t)g, (m16_lptr_t)l, 16, 0, 0); break;
+        case 1: __builtin_amdgcn_global_load_lds((m16_gptr_t)g, (m16_lptr_t)l, 16, 1024, 0); break;
+        case 2: __builtin_amdgcn_global_load_lds((m16_gptr_t)g, (m16_lptr_t)l, 16, 2048, 0); break;
+        default: __builtin_amdgcn_global_load_lds((m16_gptr_t)g, (m16_lptr_t)l, 16, 3072, 0); break;
+    }
+}
+
+struct M16State {
+    f32x4_t ot[8][4];      // O^T [d block][query block]             (AGPRs: builtin MFMAs)
+    f32x4_t st[2][2][4];   // S^T [unit kb][key block a/b][query block]  (arch VGPRs: inline-asm MFMAs)
+    bf16x8_t pf[2][4];     // P   [unit kb][query block]: keys 8G..8G+7 of the unit
+    float m_run[4], l_run[4];
+    int bad;
+};
+
+template <int OFF>
+MG_DEV void m16_rd(bf16x8_t& dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
+}
+template <int N>
+MG_DEV void m16_wait() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(N) : "memory");
+}
+// S^T accumulators live in ARCH VGPRs (the softmax reads them with VALU instructions): inline asm with "v" operands,
+// as in w64.  A block is written by groups 0-3 (a) / 4-7 (b) of a step and first read by the NEXT step's softmax.
+MG_DEV void m16_mfma_s0(f32x4_t& acc, const bf16x8_t& a, const bf16x8_t& b) {       // acc = a.b
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b));
+}
+MG_DEV void m16_mfma_s(f32x4_t& acc, const bf16x8_t& a, const bf16x8_t& b) {        // acc += a.b
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+MG_DEV void m16_mfma_s_after_valu(f32x4_t& acc, const bf16x8_t& a, const bf16x8_t& b) {   // start value written by VALU (mask)
+    asm volatile("s_nop 7\n\ts_nop 7\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+constexpr int m16_koff(int i) { return (i >> 2) * 256 + (i & 3) * 4096; }   // K fragment i = (key block i>>2, d chunk i&3)
+constexpr int m16_voff(int i) { return i * 256; }                           // V fragment i = d block
+
+// exact softmax of unit KB (true maximum of the 32 keys, rescale of O^T and l), all four query blocks
+template <int KB>
+MG_DEV void m16_softmax_exact(M16State& s, float c) {
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        float tmax = s.st[KB][0][n][0];
+#pragma unroll
+        for (int r = 1; r < 4; ++r) tmax = fmaxf(tmax, s.st[KB][0][n][r]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, s.st[KB][1][n][r]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(s.m_run[n], tmax);
+        float psum = 0.f;
+        float p[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            p[r] = __builtin_amdgcn_exp2f((s.st[KB][r >> 2][n][r & 3] - m_new) * c);
+            psum += p[r];
+        }
+        u32x4_t w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = pack_bf2(p[2 * e], p[2 * e + 1]);
+        s.pf[KB][n] = m16_bf(w);
+        const float alpha = __builtin_amdgcn_exp2f((s.m_run[n] - m_new) * c);
+        s.l_run[n] = s.l_run[n] * alpha + psum;
+#pragma unroll
+        for (int d = 0; d < 8; ++d)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s.ot[d][n][e] *= alpha;
+        s.m_run[n] = m_new;
+    }
+}
+
+// softmax of unit KB against the fixed zero reference (prologue): p = 2^s
+template <int KB>
+MG_DEV void m16_softmax_zero(M16State& s, float c) {
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        float psum = 0.f;
+        float p[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            p[r] = __builtin_amdgcn_exp2f(s.st[KB][r >> 2][n][r & 3] * c);
+            psum += p[r];
+        }
+        u32x4_t w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = pack_bf2(p[2 * e], p[2 * e + 1]);
+        s.pf[KB][n] = m16_bf(w);
+        s.l_run[n] += psum;
+        s.m_run[n] = 0.f;
+    }
+}
+
+// accumulator start of S^T for a ragged tile: -1e30 on the key rows >= lim (the MFMAs add K.Q^T to it)
+template <int KB>
+MG_DEV void m16_mask_init(M16State& s, int lim, int G) {
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = KB * 32 + G * 8 + blk * 4 + r;
+                s.st[KB][blk][n][r] = key >= lim ? -1e30f : 0.f;
+            }
+}
+
+// One pipeline step = one 32-key unit.  MFMAs: S^T of unit KB (K fragments at lds_k) when SMODE != 0 (2: masked start,
+// s.st[KB] pre-set by m16_mask_init) and P.V of unit KB (V fragments at lds_v, P = s.pf[KB]) when PV.  VALU: softmax
+// of unit 1-KB when SM.  `dma(i)` is called once per group (i = 0..7).  Fragment ring: 4 K + 4 V registers, reads two
+// groups (16 MFMAs) ahead; the reads of the first two groups must have been issued by the caller (prefetch()), the last
+// two groups of this step issue them for the NEXT step from nk / nv (0 = the clamped address of this step: data unused).
+template <int KB, int SMODE, bool PV, bool SM, bool SCALED, typename Dma>
+MG_DEV void m16_step(M16State& s, const bf16x8_t (&qf)[4][4], bf16x8_t (&kf)[4], bf16x8_t (&vf)[4], unsigned lds_k,
+                     unsigned lds_v, unsigned nk, unsigned nv, float c, Dma dma) {
+    constexpr int SB = 1 - KB;          // unit being exponentiated
+    float psa[4] = {0.f, 0.f, 0.f, 0.f}, psb[4] = {0.f, 0.f, 0.f, 0.f};
+    u32x4_t w[4];
+    float pa = 0.f, pb = 0.f;
+    // softmax of pair pp = 2i + half (16 pairs per unit): query block n = pp >> 2, packed word pp & 3 = (key block,
+    // register pair).  In two parts so that the exps sit in front of a builtin MFMA and the adds / cvt in front of an asm one.
+    auto pair_a = [&](int i, int half) __attribute__((always_inline)) {   // exp, exp
+        if (SM) {
+            const int pp = 2 * i + half, n = pp >> 2, wd = pp & 3;
+            if (SCALED) {
+                pa = __builtin_amdgcn_exp2f(s.st[SB][wd >> 1][n][(wd & 1) * 2] * c);
+                pb = __builtin_amdgcn_exp2f(s.st[SB][wd >> 1][n][(wd & 1) * 2 + 1] * c);
+            } else {
+                pa = __builtin_amdgcn_exp2f(s.st[SB][wd >> 1][n][(wd & 1) * 2]);
+                pb = __builtin_amdgcn_exp2f(s.st[SB][wd >> 1][n][(wd & 1) * 2 + 1]);
+            }
+            asm volatile("" : "+v"(pa), "+v"(pb));     // opaque use: pins the work HERE (LLVM sinks it otherwise)
+        }
+    };
+    auto pair_b = [&](int i, int half) __attribute__((always_inline)) {   // add, add, cvt_pk
+        if (SM) {
+            const int pp = 2 * i + half, n = pp >> 2, wd = pp & 3;
+            psa[n] += pa;
+            psb[n] += pb;
+            unsigned pk = pack_bf2(pa, pb);
+            asm volatile("" : "+v"(pk), "+v"(psa[n]), "+v"(psb[n]));
+            w[n][wd] = pk;
+        }
+    };
+    auto S = [&](int i, int n) __attribute__((always_inline)) {
+        const int blk = i >> 2, c = i & 3, r = i & 3;
+        if (SMODE == 1 && c == 0) m16_mfma_s0(s.st[KB][blk][n], kf[r], qf[n][c]);
+        else if (SMODE == 2 && c == 0) m16_mfma_s_after_valu(s.st[KB][blk][n], kf[r], qf[n][c]);
+        else if (SMODE != 0) m16_mfma_s(s.st[KB][blk][n], kf[r], qf[n][c]);
+    };
+    auto P = [&](int i, int n) __attribute__((always_inline)) {
+        if (PV) s.ot[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[i & 3], s.pf[KB][n], s.ot[i][n], 0, 0, 0);
+    };
+#define M16_SB() __builtin_amdgcn_sched_barrier(0)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r2 = (i + 2) & 3;
+        m16_wait<2>();                         // K(i) and V(i) landed; younger: K(i+1), V(i+1)
+        M16_SB();
+        S(i, 0);
+        M16_SB();
+        pair_a(i, 0);
+        M16_SB();
+        P(i, 0);
+        M16_SB();
+        pair_b(i, 0);
+        M16_SB();
+        S(i, 1);
+        M16_SB();
+        // ring slot (i+2)&3 was consumed two groups ago: it takes the read for group i+2.  (A ds_read whose result
+        // nobody uses would leave its destination free for reuse while the data is still on its way: steps without
+        // S^T MFMAs keep the previous occupant alive up to here.)
+        if (SMODE == 0) asm volatile("" ::"v"(kf[r2]));
+        if (i < 6) {
+            switch (i) {   // compile-time after unrolling
+                case 0: m16_rd<m16_koff(2)>(kf[r2], lds_k); break;
+                case 1: m16_rd<m16_koff(3)>(kf[r2], lds_k); break;
+                case 2: m16_rd<m16_koff(4)>(kf[r2], lds_k); break;
+                case 3: m16_rd<m16_koff(5)>(kf[r2], lds_k); break;
+                case 4: m16_rd<m16_koff(6)>(kf[r2], lds_k); break;
+                default: m16_rd<m16_koff(7)>(kf[r2], lds_k); break;
+            }
+        } else if (i == 6) m16_rd<m16_koff(0)>(kf[r2], nk);
+        else m16_rd<m16_koff(1)>(kf[r2], nk);
+        M16_SB();
+        P(i, 1);
+        M16_SB();
+        if (i < 6) {
+            switch (i) {
+                case 0: m16_rd<m16_voff(2)>(vf[r2], lds_v); break;
+                case 1: m16_rd<m16_voff(3)>(vf[r2], lds_v); break;
+                case 2: m16_rd<m16_voff(4)>(vf[r2], lds_v); break;
+                case 3: m16_rd<m16_voff(5)>(vf[r2], lds_v); break;
+                case 4: m16_rd<m16_voff(6)>(vf[r2], lds_v); break;
+                default: m16_rd<m16_voff(7)>(vf[r2], lds_v); break;
+            }
+        } else if (i == 6) m16_rd<m16_voff(0)>(vf[r2], nv);
+        else m16_rd<m16_voff(1)>(vf[r2], nv);
+        M16_SB();
+        S(i, 2);
+        M16_SB();
+        pair_a(i, 1);
+        M16_SB();
+        P(i, 2);
+        M16_SB();
+        pair_b(i, 1);
+        M16_SB();
+        S(i, 3);
+        M16_SB();
+        dma(i);
+        M16_SB();
+        P(i, 3);
+        M16_SB();
+    }
+#undef M16_SB
+    if (SM) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            s.l_run[n] += psa[n] + psb[n];     // (l only grows, inf / NaN are sticky: ONE range test of the final sum)
+            s.pf[SB][n] = m16_bf(w[n]);
+        }
+    }
+}
+
+struct M16NoDma {
+    __device__ __forceinline__ void operator()(int) const {}
+};
+
+template <bool PROF, bool SCALED>
+__global__ __launch_bounds__(M16_THREADS, 1) void attn_hd128_m16_kernel(
+    const uint16_t* __restrict__ q, int64_t ldq, const uint16_t* __restrict__ kp, const uint16_t* __restrict__ vp,
+    uint16_t* __restrict__ o, int64_t ldo, int64_t Lq, int64_t Lk, int heads, float c_log2, int nqb, int dbg,
+    unsigned long long* __restrict__ prof, float* __restrict__ lse, unsigned* __restrict__ flagcnt) {
+    __shared__ __attribute__((aligned(16))) char smem[6 * M16_TILE];
+    const int bid = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, qi = lane & 15, G = lane >> 4;
+    // persistent, XCD-aware work loop over (head, query block) items, head-major (see attn_hd128_w64.hip)
+    const int total_items = nqb * heads;
+    const int nwg = gridDim.x;
+    int item, item_end, item_step;
+    if (nwg == total_items) {
+        item = bid, item_end = bid + 1, item_step = 1;
+    } else {
+        const int xcd = bid & 7, slot = bid >> 3;
+        item = (int)((int64_t)xcd * total_items / 8) + slot;
+        item_end = (int)((int64_t)(xcd + 1) * total_items / 8);
+        item_step = nwg >> 3;           // host guarantees nwg % 8 == 0 here
+    }
+    for (; item < item_end; item += item_step) {
+    const int head = item / nqb;
+    const int qb0 = item - head * nqb;
+    __syncthreads();                    // the previous item's last LDS reads are done before this one's DMA
+
+    // Q fragments (B operand): query block n of this wave = rows 64*wave + 16*n + qi, d = 32*c + 8*G .. +7
+    bf16x8_t qf[4][4];
+    const int64_t qrow_base = (int64_t)qb0 * M16_QB + wave * 64 + qi;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int64_t qr = qrow_base + n * 16;
+        const int64_t qrow = qr < Lq ? qr : Lq - 1;
+        const uint16_t* qp = q + qrow * ldq + head * 128 + G * 8;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) qf[n][c] = m16_bf(*(const u32x4_t*)(qp + c * 32));
+    }
+    const int T = (int)((Lk + 63) / 64);
+    const int last_lim = (int)(Lk - (int64_t)(T - 1) * 64);     // keys in the last tile, 1..64
+    // LDS-DMA: a tile is 16 pieces of 1 KiB; wave w moves pieces 4w..4w+3 of the K tile and of the V tile
+    const char* k_src = (const char*)(kp + ((int64_t)head * T) * 8192 + wave * 2048);   // wave-uniform (SGPRs)
+    const char* v_src = (const char*)(vp + ((int64_t)head * T) * 8192 + wave * 2048);
+    const unsigned lane_off = lane * 16;                                                  // the only per-lane part
+    const int nfull = last_lim == 64 ? T : T - 1;
+    // tile indices past the end are clamped (a redundant reload of the last tile into a free slot) instead of guarded
+    const unsigned lds0 = (unsigned)(uintptr_t)(m16_lptr_t)smem;
+    auto dma_k = [&](int t, int slot, int n) __attribute__((always_inline)) {
+        const int tt = t < T ? t : T - 1;
+        m16_glds16_n(k_src + (int64_t)tt * 16384 + lane_off, smem + M16_K(slot) + wave * 4096, n);
+    };
+    auto dma_v = [&](int t, int slot, int n) __attribute__((always_inline)) {
+        const int tt = t < T ? t : T - 1;
+        m16_glds16_n(v_src + (int64_t)tt * 16384 + lane_off, smem + M16_V(slot) + wave * 4096, n);
+    };
+    const unsigned kbase = lds0 + G * 1024 + qi * 16;                  // + M16_K(slot) + kb*512 + blk*256 + c*4096
+    const unsigned vbase = lds0 + 3 * M16_TILE + G * 2048 + qi * 16;   // + slot*TILE + kb*8192 + db*256
+    auto k_addr = [&](int slot, int kb) __attribute__((always_inline)) { return kbase + slot * M16_TILE + kb * 512; };
+    auto v_addr = [&](int slot, int kb) __attribute__((always_inline)) { return vbase + slot * M16_TILE + kb * 8192; };
+
+    M16State s;
+    bf16x8_t kf[4], vf[4];
+    auto reset = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int d = 0; d < 8; ++d)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) s.ot[d][n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int n = 0; n < 4; ++n) s.m_run[n] = -1e30f, s.l_run[n] = 0.f;
+        s.bad = 0;
+    };
+    reset();
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) asm volatile("" : "+v"(qf[n][c]));
+    auto fence = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+    // hot-loop form: this wave's LDS-DMA pieces have landed, then the barrier — and nothing else (no lgkmcnt(0): four
+    // fragment reads are in flight across the barrier by design)
+    auto fence_hot = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+    auto prefetch = [&](unsigned ak, unsigned av) __attribute__((always_inline)) {
+        m16_rd<m16_koff(0)>(kf[0], ak);
+        m16_rd<m16_voff(0)>(vf[0], av);
+        m16_rd<m16_koff(1)>(kf[1], ak);
+        m16_rd<m16_voff(1)>(vf[1], av);
+    };
+    // bare S^T of one unit (prologue / exact loop): 32 MFMAs, plain loads
+    auto bare_S = [&](auto kbc, int slot, int lim) __attribute__((always_inline)) {
+        constexpr int KB = decltype(kbc)::value;
+        if (lim < 64) m16_mask_init<KB>(s, lim, G);
+        else {
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) s.st[KB][blk][n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        }
+        const char* base = smem + M16_K(slot) + G * 1024 + qi * 16 + KB * 512;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const bf16x8_t f = *(const bf16x8_t*)(base + m16_koff(i));
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                s.st[KB][i >> 2][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f, qf[n][i & 3], s.st[KB][i >> 2][n], 0, 0, 0);
+        }
+    };
+    auto bare_PV = [&](auto kbc, int slot) __attribute__((always_inline)) {
+        constexpr int KB = decltype(kbc)::value;
+        const char* base = smem + M16_V(slot) + G * 2048 + qi * 16 + KB * 8192;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const bf16x8_t f = *(const bf16x8_t*)(base + m16_voff(i));
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                s.ot[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f, s.pf[KB][n], s.ot[i][n], 0, 0, 0);
+        }
+    };
+    using KB0 = std::integral_constant<int, 0>;
+    using KB1 = std::integral_constant<int, 1>;
+
+    // ------------------------------------------------------------------------------------------
+    // pipelined pass.  Iteration t = steps u = 2t (S(t,1) | P.V(t-1,1) | softmax S(t,0)) and
+    // u = 2t+1 (S(t+1,0) | P.V(t,0) | softmax S(t,1)); tile t in slot t % 3.  Needs >= 3 FULL
+    // tiles to have a steady state; shorter or all-ragged rows go straight to the exact loop.
+    // ------------------------------------------------------------------------------------------
+    bool exact_pass = nfull < 3;
+    if (!exact_pass) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) dma_k(0, 0, n), dma_v(0, 0, n), dma_k(1, 1, n);
+        fence();
+#pragma unroll
+        for (int n = 0; n < 4; ++n) dma_k(2, 2, n), dma_v(1, 1, n);     // iteration 0's refill
+        bare_S(KB0{}, 0, 64);
+        m16_softmax_zero<0>(s, c_log2);
+        bare_S(KB1{}, 0, 64);
+        // step u = 1: S(1,0) | P.V(0,0) | softmax S(0,1)
+        prefetch(k_addr(1, 0), v_addr(0, 0));
+        m16_step<0, 1, true, true, SCALED>(s, qf, kf, vf, k_addr(1, 0), v_addr(0, 0), k_addr(1, 1), v_addr(0, 1), c_log2, M16NoDma());
+        int s0 = 0, s1 = 1, s2 = 2;     // slots of tiles t-1, t, t+1
+        int t = 1;
+        unsigned long long pf_fence = 0, pf_a = 0, pf_b = 0, pf_n = 0;
+        for (; t + 1 < nfull; ++t) {
+            const unsigned long long c0 = PROF ? __builtin_amdgcn_s_memtime() : 0;
+            fence_hot();                // K(t+1), V(t) visible; everyone is past iteration t-1
+            const unsigned long long c1 = PROF ? __builtin_amdgcn_s_memtime() : 0;
+            // u = 2t: S(t,1) [K slot s1] | P.V(t-1,1) [V slot s0] | softmax S(t,0); refill K(t+2) -> slot s0, V(t+1) -> slot s2
+            m16_step<1, 1, true, true, SCALED>(s, qf, kf, vf, k_addr(s1, 1), v_addr(s0, 1), k_addr(s2, 0), v_addr(s1, 0), c_log2,
+                                       [&](int n) __attribute__((always_inline)) {   // all 8 refill pieces here:
+                                           if (n < 4) dma_k(t + 2, s0, n);            // K(t+2) -> slot of tile t-1,
+                                           else dma_v(t + 1, s2, n - 4);              // V(t+1) -> slot of tile t-2;
+                                       });                                            // step B gives them time to land
+            const unsigned long long c2 = PROF ? __builtin_amdgcn_s_memtime() : 0;
+            // u = 2t+1: S(t+1,0) [K slot s2] | P.V(t,0) [V slot s1] | softmax S(t,1)
+            m16_step<0, 1, true, true, SCALED>(s, qf, kf, vf, k_addr(s2, 0), v_addr(s1, 0), k_addr(s2, 1), v_addr(s1, 1), c_log2, M16NoDma());
+            if (PROF) {
+                const unsigned long long c3 = __builtin_amdgcn_s_memtime();
+                pf_fence += c1 - c0, pf_a += c2 - c1, pf_b += c3 - c2, pf_n += 1;
+            }
+            const int tmp = s0;
+            s0 = s1, s1 = s2, s2 = tmp;
+        }
+        if (PROF && prof && lane == 0) {
+            atomicAdd(prof + wave * 4 + 0, pf_fence);
+            atomicAdd(prof + wave * 4 + 1, pf_a);
+            atomicAdd(prof + wave * 4 + 2, pf_b);
+            atomicAdd(prof + wave * 4 + 3, pf_n);
+        }
+        // here t == nfull - 1 (last full tile), S(t,0) is complete, P(t-1,1) is ready, ring primed for u = 2t
+        fence();
+        if (t + 1 < T) {                // a ragged tile t+1 follows: its V is staged now (slot s2)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) dma_v(t + 1, s2, n);
+        }
+        m16_step<1, 1, true, true, SCALED>(s, qf, kf, vf, k_addr(s1, 1), v_addr(s0, 1), k_addr(s2, 0), v_addr(s1, 0), c_log2, M16NoDma());
+        if (t + 1 < T) {
+            // u = 2t+1 with the masked start for S(t+1,0)
+            m16_mask_init<0>(s, last_lim, G);
+            m16_step<0, 2, true, true, SCALED>(s, qf, kf, vf, k_addr(s2, 0), v_addr(s1, 0), k_addr(s2, 1), v_addr(s1, 1), c_log2, M16NoDma());
+            fence();                    // V(t+1) landed
+            // u = 2t+2: S(t+1,1) masked | P.V(t,1) | softmax S(t+1,0)
+            m16_mask_init<1>(s, last_lim, G);
+            m16_step<1, 2, true, true, SCALED>(s, qf, kf, vf, k_addr(s2, 1), v_addr(s1, 1), k_addr(s2, 1), v_addr(s2, 0), c_log2, M16NoDma());
+            // u = 2t+3: P.V(t+1,0) | softmax S(t+1,1)
+            m16_step<0, 0, true, true, SCALED>(s, qf, kf, vf, k_addr(s2, 1), v_addr(s2, 0), k_addr(s2, 1), v_addr(s2, 1), c_log2, M16NoDma());
+            // u = 2t+4: P.V(t+1,1)
+            m16_step<1, 0, true, false, SCALED>(s, qf, kf, vf, k_addr(s2, 1), v_addr(s2, 1), k_addr(s2, 1), v_addr(s2, 1), c_log2, M16NoDma());
+        } else {
+            // u = 2t+1: P.V(t,0) | softmax S(t,1)
+            m16_step<0, 0, true, true, SCALED>(s, qf, kf, vf, k_addr(s1, 1), v_addr(s1, 0), k_addr(s1, 1), v_addr(s1, 1), c_log2, M16NoDma());
+            // u = 2t+2: P.V(t,1)
+            m16_step<1, 0, true, false, SCALED>(s, qf, kf, vf, k_addr(s1, 1), v_addr(s1, 1), k_addr(s1, 1), v_addr(s1, 1), c_log2, M16NoDma());
+        }
+        m16_wait<0>();
+        // the last prefetches of the chain are never consumed: keep the ring alive until they have landed
+        asm volatile("" ::"v"(kf[0]), "v"(kf[1]), "v"(kf[2]), "v"(kf[3]), "v"(vf[0]), "v"(vf[1]), "v"(vf[2]), "v"(vf[3]));
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {       // absolute scale: ONE range test of the final row sums (2^-60 .. 2^90; inf / NaN too)
+            float lt = s.l_run[n] + __shfl_xor(s.l_run[n], 16, 64);
+            lt += __shfl_xor(lt, 32, 64);
+            s.bad |= !(lt >= 8.6736174e-19f && lt <= 1.2379400e27f);
+        }
+        exact_pass = __syncthreads_or(s.bad) != 0;      // workgroup-uniform: the exact loop has barriers
+        if (exact_pass && flagcnt && tid == 0) atomicAdd(flagcnt, 1u);      // debug hook: how many blocks were redone
+        if (dbg & 1) exact_pass = false;                // debug: keep the pipelined result even when flagged
+    }
+    // ------------------------------------------------------------------------------------------
+    // exact pass: plain one-slot loop, true maxima; short rows, and blocks whose pipelined pass flagged
+    // ------------------------------------------------------------------------------------------
+    if (exact_pass) {
+        reset();
+        for (int t = 0; t < T; ++t) {
+            __syncthreads();
+#pragma unroll
+            for (int n = 0; n < 4; ++n) dma_k(t, 0, n), dma_v(t, 0, n);
+            fence();
+            const int lim = t == T - 1 ? last_lim : 64;
+            bare_S(KB0{}, 0, lim);
+            bare_S(KB1{}, 0, lim);
+            m16_softmax_exact<0>(s, c_log2);            // P of a unit is relative to the maximum at ITS softmax:
+            bare_PV(KB0{}, 0);                  // it must reach O^T before the next rescale
+            m16_softmax_exact<1>(s, c_log2);
+            bare_PV(KB1{}, 0);
+        }
+    }
+
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        float l_tot = s.l_run[n] + __shfl_xor(s.l_run[n], 16, 64);
+        l_tot += __shfl_xor(l_tot, 32, 64);
+        const float inv = 1.f / l_tot;
+        const int64_t qr = (int64_t)qb0 * M16_QB + wave * 64 + n * 16 + qi;
+        if (lse && G == 0 && qr < Lq) lse[(int64_t)head * Lq + qr] = (s.m_run[n] * c_log2 + __log2f(l_tot)) * 0.6931471805599453f;
+        if (qr < Lq) {
+            uint16_t* op = o + qr * ldo + head * 128 + G * 4;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+                uint2 pk;
+                pk.x = pack_bf2(s.ot[d][n][0] * inv, s.ot[d][n][1] * inv);
+                pk.y = pack_bf2(s.ot[d][n][2] * inv, s.ot[d][n][3] * inv);
+                *(uint2*)(op + d * 16) = pk;
+            }
+        }
+    }
+    }   // work loop
+}
+
+static int g_m16_dbg = 0;
+static unsigned long long* g_m16_prof = nullptr;
+static unsigned* g_m16_flagcnt = nullptr;
+void mg_attn_m16_hooks(int dbg, unsigned long long* prof, unsigned* flagcnt) { g_m16_dbg = dbg, g_m16_prof = prof, g_m16_flagcnt = flagcnt; }
+
+// c_log2 = scale*log2(e) of the scores; prescaled != 0: q already carries that factor (mg_rmsnorm_rope_bf16 out_scale).
+// kp must be in the m16 row order (mg_pack_kv_bf16 with the m16 kernel selected).
+int mg_attn_m16_launch(const uint16_t* q, int64_t ldq, const uint16_t* kp, const uint16_t* vp, uint16_t* o, int64_t ldo,
+                       int64_t Lq, int64_t Lk, int heads, float c_log2, int prescaled, int nqb, float* lse, hipStream_t st) {
+    int n_cu = mg_cu_count();
+    if (n_cu < 0) return MG_ERR_LAUNCH;
+    n_cu &= ~7;                                         // one workgroup per CU (96 KiB LDS), a multiple of the 8 XCDs
+    if (n_cu < 8) n_cu = 8;
+    const int total = nqb * heads;
+    const unsigned grid = total <= n_cu ? (unsigned)total : (unsigned)n_cu;   // persistent when there is more work than CUs
+#define M16_LAUNCH(PROF, SCALED)                                                                                             \
+    hipLaunchKernelGGL((attn_hd128_m16_kernel<PROF, SCALED>), dim3(grid), dim3(M16_THREADS), 0, st, q, ldq, kp, vp, o, ldo, Lq, \
+                       Lk, heads, prescaled ? 1.0f : c_log2, nqb, g_m16_dbg, PROF ? g_m16_prof : nullptr, lse, g_m16_flagcnt)
+    if (g_m16_prof) {
+        if (prescaled) M16_LAUNCH(true, false);
+        else M16_LAUNCH(true, true);
+    } else {
+        if (prescaled) M16_LAUNCH(false, false);
+        else M16_LAUNCH(false, true);
+    }
+#undef M16_LAUNCH
+    return mg_check_launch();
+}

@@ -1,3 +1,5 @@
+// A/B PARTNER of attn_hd128_m16.hip since round 3 (mg_attn_set_variant(3)): the round-2 kernel, unchanged — it needs
+// the K tiles in natural row order (mg_pack_kv_bf16 follows the selection).
 // Flash-style attention forward, head_dim 128 — schedule "w64": 4 waves x 64 queries, ONE wave per
 // SIMD, software-pipelined in half-tile units.  Same operands and math as attn_hd128.hip (packed
 // K/V tiles, S^T = K.Q^T, maximum-free softmax against the running reference, O^T accumulators).
@@ -243,7 +245,8 @@ struct W64NoDma {
 template <bool PROF>
 __global__ __launch_bounds__(W64_THREADS, 1) void attn_hd128_w64_kernel(
     const uint16_t* __restrict__ q, int64_t ldq, const uint16_t* __restrict__ kp, const uint16_t* __restrict__ vp,
-    uint16_t* __restrict__ o, int64_t ldo, int64_t Lq, int64_t Lk, int heads, float c_log2, int nqb, int dbg, unsigned long long* __restrict__ prof, float* __restrict__ lse) {
+    uint16_t* __restrict__ o, int64_t ldo, int64_t Lq, int64_t Lk, int heads, float c_log2, int nqb, int dbg, unsigned long long* __restrict__ prof, float* __restrict__ lse,
+    unsigned* __restrict__ flagcnt) {
     __shared__ __attribute__((aligned(16))) char smem[6 * W64_TILE];
     const int bid = blockIdx.x;
     const int tid = threadIdx.x;
@@ -460,6 +463,7 @@ __global__ __launch_bounds__(W64_THREADS, 1) void attn_hd128_w64_kernel(
         // the last prefetches of the chain are never consumed: keep the ring alive until they have landed
         asm volatile("" ::"v"(kf[0]), "v"(kf[1]), "v"(kf[2]), "v"(kf[3]), "v"(vf[0]), "v"(vf[1]), "v"(vf[2]), "v"(vf[3]));
         exact_pass = __syncthreads_or(s.bad) != 0;      // workgroup-uniform: the exact loop has barriers
+        if (exact_pass && flagcnt && tid == 0) atomicAdd(flagcnt, 1u);      // debug hook: how many blocks were redone
         if (dbg & 1) exact_pass = false;                // debug: keep the pipelined result even when flagged
     }
     // ------------------------------------------------------------------------------------------
@@ -507,26 +511,26 @@ __global__ __launch_bounds__(W64_THREADS, 1) void attn_hd128_w64_kernel(
 
 static int g_w64_dbg = 0;
 static unsigned long long* g_w64_prof = nullptr;
-extern "C" void mg_attn_w64_profile(unsigned long long* dev_buf) { g_w64_prof = dev_buf; }   // debug hook: 4 waves x {fence, step A, step B, iterations}
-extern "C" void mg_attn_w64_debug(int flags) { g_w64_dbg = flags; }   // debug hook, not in the public header
+static unsigned* g_w64_flagcnt = nullptr;
+void mg_attn_m16_hooks(int dbg, unsigned long long* prof, unsigned* flagcnt);
+static void w64_sync_hooks() { mg_attn_m16_hooks(g_w64_dbg, g_w64_prof, g_w64_flagcnt); }   // the m16 kernel shares the three hooks
+extern "C" void mg_attn_w64_profile(unsigned long long* dev_buf) { g_w64_prof = dev_buf; w64_sync_hooks(); }   // debug hook: 4 waves x {fence, step A, step B, iterations}
+extern "C" void mg_attn_w64_debug(int flags) { g_w64_dbg = flags; w64_sync_hooks(); }
+extern "C" void mg_attn_w64_flag_counter(unsigned* dev_counter) { g_w64_flagcnt = dev_counter; w64_sync_hooks(); }   // debug hook: += query blocks redone by the exact pass
 
 int mg_attn_w64_launch(const uint16_t* q, int64_t ldq, const uint16_t* kp, const uint16_t* vp, uint16_t* o, int64_t ldo,
                        int64_t Lq, int64_t Lk, int heads, float c_log2, int nqb, float* lse, hipStream_t st) {
-    static int n_cu = 0;
-    if (!n_cu) {
-        hipDeviceProp_t prop;
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return MG_ERR_LAUNCH;
-        n_cu = prop.multiProcessorCount & ~7;          // one workgroup per CU (96 KiB LDS), a multiple of the 8 XCDs
-        if (n_cu < 8) n_cu = 8;
-    }
+    int n_cu = mg_cu_count();
+    if (n_cu < 0) return MG_ERR_LAUNCH;
+    n_cu &= ~7;                                         // one workgroup per CU (96 KiB LDS), a multiple of the 8 XCDs
+    if (n_cu < 8) n_cu = 8;
     const int total = nqb * heads;
     const unsigned grid = total <= n_cu ? (unsigned)total : (unsigned)n_cu;   // persistent when there is more work than CUs
     if (g_w64_prof)
         hipLaunchKernelGGL((attn_hd128_w64_kernel<true>), dim3(grid), dim3(W64_THREADS), 0, st, q, ldq, kp, vp, o, ldo, Lq, Lk,
-                           heads, c_log2, nqb, g_w64_dbg, g_w64_prof, lse);
+                           heads, c_log2, nqb, g_w64_dbg, g_w64_prof, lse, g_w64_flagcnt);
     else
         hipLaunchKernelGGL((attn_hd128_w64_kernel<false>), dim3(grid), dim3(W64_THREADS), 0, st, q, ldq, kp, vp, o, ldo, Lq, Lk,
-                           heads, c_log2, nqb, g_w64_dbg, nullptr, lse);
+                           heads, c_log2, nqb, g_w64_dbg, nullptr, lse, g_w64_flagcnt);
     return mg_check_launch();
 }

@@ -68,6 +68,16 @@ MG_DEV float gelu_tanh(float x) {
 }
 MG_DEV float silu(float x) { return x / (1.f + __expf(-x)); }
 
+// CUs of the CURRENT device, asked per call (an attribute lookup; a function-static cache would be wrong in a process
+// that drives devices of different sizes and racy on first use from two threads); -1 on error
+static inline int mg_cu_count() {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return -1;
+    return n;
+}
+
 static inline int mg_check_launch() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MG_OK : MG_ERR_LAUNCH;

@@ -102,7 +102,7 @@ template <int MAXC>
 __global__ __launch_bounds__(NT) void rmsnorm_rope_kernel(
     const uint16_t* __restrict__ x, int64_t ldx, uint16_t* __restrict__ out, int64_t ldo, int64_t rows,
     int dim, const float* __restrict__ weight, float eps, int head_dim, const float2* __restrict__ rope_cs,
-    int F, int H, int W, int64_t pos0) {
+    int F, int H, int W, int64_t pos0, float out_scale) {
     __shared__ float red[NT / 64];
     __shared__ float2 cs_row[128];          // the token's (cos, sin) pairs, identical for every head: staged once per row
     const int nc = dim >> 3;
@@ -156,11 +156,12 @@ __global__ __launch_bounds__(NT) void rmsnorm_rope_kernel(
                         y[2 * j + 1] = a * cs.y + b * cs.x;
                     }
                 }
+                // out_scale (1 = none: exact): the attention's scale*log2(e) folded into q BEFORE its one rounding to bf16
                 u32x4_t o;
-                o[0] = pack_bf2(y[0], y[1]);
-                o[1] = pack_bf2(y[2], y[3]);
-                o[2] = pack_bf2(y[4], y[5]);
-                o[3] = pack_bf2(y[6], y[7]);
+                o[0] = pack_bf2(y[0] * out_scale, y[1] * out_scale);
+                o[1] = pack_bf2(y[2] * out_scale, y[3] * out_scale);
+                o[2] = pack_bf2(y[4] * out_scale, y[5] * out_scale);
+                o[3] = pack_bf2(y[6] * out_scale, y[7] * out_scale);
                 ((u32x4_t*)(out + row * ldo))[ch] = o;
             }
         }
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(NT) void rmsnorm_rope_kernel(
 
 extern "C" int mg_rmsnorm_rope_bf16(const uint16_t* x, int64_t ldx, uint16_t* out, int64_t ldo,
                                     int64_t rows, int dim, const float* weight, float eps, int head_dim,
-                                    const float* rope_cs, int F, int H, int W, int64_t pos0,
+                                    const float* rope_cs, int F, int H, int W, int64_t pos0, float out_scale,
                                     void* stream) {
     if (rows == 0) return MG_OK;
     if (!x || !out || !weight) return MG_ERR_ARG;
@@ -185,13 +186,13 @@ extern "C" int mg_rmsnorm_rope_bf16(const uint16_t* x, int64_t ldx, uint16_t* ou
     const float2* cs = (const float2*)rope_cs;
     if (nc <= NT)
         hipLaunchKernelGGL(rmsnorm_rope_kernel<1>, dim3(grid), dim3(NT), 0, st, x, ldx, out, ldo, rows, dim,
-                           weight, eps, head_dim, cs, F, H, W, pos0);
+                           weight, eps, head_dim, cs, F, H, W, pos0, out_scale);
     else if (nc <= 3 * NT)
         hipLaunchKernelGGL(rmsnorm_rope_kernel<3>, dim3(grid), dim3(NT), 0, st, x, ldx, out, ldo, rows, dim,
-                           weight, eps, head_dim, cs, F, H, W, pos0);
+                           weight, eps, head_dim, cs, F, H, W, pos0, out_scale);
     else
         hipLaunchKernelGGL(rmsnorm_rope_kernel<4>, dim3(grid), dim3(NT), 0, st, x, ldx, out, ldo, rows, dim,
-                           weight, eps, head_dim, cs, F, H, W, pos0);
+                           weight, eps, head_dim, cs, F, H, W, pos0, out_scale);
     return mg_check_launch();
 }
 
@@ -462,4 +463,4 @@ extern "C" int mg_gate_residual_f32(float* x, int64_t ldx, const uint16_t* y, in
 }
 
 extern "C" const char* mg_version(void) { return "moviigen_hip 3 gfx950"; }
-extern "C" int mg_abi_version(void) { return 3; }   // 3 = 2 + the exchange layouts, mg_gate_residual_f32, mg_image_to_u8 (additions only)
+extern "C" int mg_abi_version(void) { return 4; }   // 4: mg_rmsnorm_rope_bf16 gained out_scale, mg_pack_kv_bf16's K row order follows the 16x16x32 attention kernel, + mg_attn_fwd_bf16_hd128_prescaled

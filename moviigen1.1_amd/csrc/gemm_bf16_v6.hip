@@ -190,14 +190,10 @@ __global__ __launch_bounds__(V6_THREADS, 1) void gemm_bf16_v6_kernel(
 
 int mg_gemm_v6_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_t ldw, const float* bias, int64_t M,
                       int N, int K, int epilogue, void* out, int64_t ldo, const float* gate, hipStream_t st) {
-    static int n_cu = 0;
-    if (!n_cu) {
-        hipDeviceProp_t prop;
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return MG_ERR_LAUNCH;
-        n_cu = prop.multiProcessorCount & ~7;          // one workgroup per CU (128 KiB LDS), a multiple of the 8 XCDs
-        if (n_cu < 8) n_cu = 8;
-    }
+    int n_cu = mg_cu_count();
+    if (n_cu < 0) return MG_ERR_LAUNCH;
+    n_cu &= ~7;                                         // one workgroup per CU (128 KiB LDS), a multiple of the 8 XCDs
+    if (n_cu < 8) n_cu = 8;
     const int64_t tiles_m64 = (M + V6_BM - 1) / V6_BM;
     const int tiles_n = (N + V6_BN - 1) / V6_BN;
     if (tiles_m64 * tiles_n > 0x7fffffffLL) return MG_ERR_SHAPE;

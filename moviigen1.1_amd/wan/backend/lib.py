@@ -16,15 +16,15 @@ SIGNATURES = {
     'mg_abi_version': [],
     'mg_ln_modulate': [c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_int, c_f32, c_int, c_vp, c_int, c_i64, c_vp],
     'mg_rmsnorm_rope_bf16': [c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_vp, c_f32, c_int, c_vp, c_int, c_int,
-                             c_int, c_i64, c_vp],
+                             c_int, c_i64, c_f32, c_vp],
     'mg_pack_kv_bf16': [c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_int, c_vp, c_vp, c_vp],
     'mg_gemm_bf16': [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_vp],
     'mg_attn_fwd_bf16_hd128': [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_f32, c_vp],
     'mg_attn_fwd_bf16_hd128_lse': [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_f32, c_vp],
+    'mg_attn_fwd_bf16_hd128_prescaled': [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_vp],
     'mg_attn_merge_f32': [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_vp],
     'mg_attn_fwd_bf16_generic': [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_int, c_int,
                                  c_f32, c_vp],
-    'mg_attn_set_lazy_rescale': [c_int],
     'mg_attn_set_variant': [c_int],
     'mg_gemm_set_variant': [c_int],
     'mg_sinusoid_embed': [c_vp, c_int, c_int, c_int, c_vp, c_vp],
@@ -56,9 +56,9 @@ SIGNATURES = {
     'mg_shard_all_gather': [c_vp, c_vp, c_vp, c_i64, c_vp],
     'mg_gate_residual_f32': [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int, c_vp],
     # debug / profiling hooks (declared in the header's last section; never called by the product path)
-    'mg_attn_debug_profile': [c_vp],
     'mg_attn_w64_profile': [c_vp],
     'mg_attn_w64_debug': [c_int],
+    'mg_attn_w64_flag_counter': [c_vp],
     'mg_gemm_debug_profile': [c_vp],
     'mg_gemm5_debug_profile': [c_vp],
     'mg_image_to_u8': [c_vp, c_int, c_int, c_f32, c_f32, c_vp, c_vp],
@@ -66,9 +66,9 @@ SIGNATURES = {
     'mg_sp_copy_blocks_bf16': [c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_int, c_i64, c_int, c_vp],
     'mg_sp_unpack_o_bf16': [c_vp, c_i64, c_int, c_int, c_int, c_int, c_vp, c_i64, c_vp],
 }
-_RESTYPE = {'mg_version': ctypes.c_char_p, 'mg_vae_attn_workspace_floats': ctypes.c_int64, 'mg_attn_set_lazy_rescale': None, 'mg_attn_set_variant': None,
-            'mg_gemm_set_variant': None, 'mg_attn_debug_profile': None, 'mg_attn_w64_profile': None,
-            'mg_attn_w64_debug': None, 'mg_gemm_debug_profile': None, 'mg_gemm5_debug_profile': None}
+_RESTYPE = {'mg_version': ctypes.c_char_p, 'mg_vae_attn_workspace_floats': ctypes.c_int64, 'mg_attn_set_variant': None,
+            'mg_gemm_set_variant': None, 'mg_attn_w64_profile': None,
+            'mg_attn_w64_debug': None, 'mg_attn_w64_flag_counter': None, 'mg_gemm_debug_profile': None, 'mg_gemm5_debug_profile': None}
 DEFAULT_GEMM_VARIANT = 0   # must match g_gemm_variant in csrc/gemm_bf16.hip (0 = by shape and epilogue)
 
 ERRORS = {-1: 'MG_ERR_ARG (null pointer / bad enum)', -2: 'MG_ERR_SHAPE (unsupported shape or alignment)',
@@ -97,10 +97,6 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.argtypes = args
         fn.restype = _RESTYPE.get(name, ctypes.c_int)
-    # A/B switches for measurements (tools/): kernel selections of the GEMM and the attention
-    for env, fn in (('MOVIIGEN_GEMM_VARIANT', 'mg_gemm_set_variant'), ('MOVIIGEN_ATTN_VARIANT', 'mg_attn_set_variant')):
-        if os.environ.get(env):
-            getattr(lib, fn)(int(os.environ[env]))
     _lib = lib
     return lib
 

@@ -38,12 +38,16 @@ def ln_modulate(x, scale, shift, add_one, eps, out, round_norm_bf16=False):
     return out
 
 
-def rmsnorm_rope(x, weight, eps, head_dim, out, rope_cs=None, grid=(1, 1, 1), pos0=0):
-    """x [rows, dim] bf16 (may be a strided column slice) -> out bf16."""
+ATTN_LOG2E = 1.4426950408889634
+
+
+def rmsnorm_rope(x, weight, eps, head_dim, out, rope_cs=None, grid=(1, 1, 1), pos0=0, out_scale=1.0):
+    """x [rows, dim] bf16 (may be a strided column slice) -> out bf16.  out_scale: factor applied before the one
+    rounding to bf16 (the attention's scale*log2(e) for a q that goes to attention_hd128(..., prescaled=True))."""
     _chk(x, torch.bfloat16, 'x'); _chk(out, torch.bfloat16, 'out'); _chk(weight, torch.float32, 'weight')
     rows, dim = x.shape
     lib.call('mg_rmsnorm_rope_bf16', _p(x), x.stride(0), _p(out), out.stride(0), rows, dim, _p(weight), float(eps),
-             int(head_dim), _p(rope_cs), int(grid[0]), int(grid[1]), int(grid[2]), int(pos0), _st())
+             int(head_dim), _p(rope_cs), int(grid[0]), int(grid[1]), int(grid[2]), int(pos0), float(out_scale), _st())
     return out
 
 
@@ -80,14 +84,19 @@ def gemm(a, w, bias, epilogue, out, gate=None):
     return out
 
 
-def attention_hd128(q, kp, vp, out, lk, heads, scale):
-    """q [Lq, >=heads*128] bf16; kp/vp from pack_kv for the same lk keys; out [Lq, >=heads*128]."""
+def attention_hd128(q, kp, vp, out, lk, heads, scale, prescaled=False):
+    """q [Lq, >=heads*128] bf16; kp/vp from pack_kv for the same lk keys; out [Lq, >=heads*128].
+    prescaled: q was produced with rmsnorm_rope(out_scale=scale * ATTN_LOG2E) — `scale` is then only documentation."""
     _chk(q, torch.bfloat16, 'q'); _chk(kp, torch.bfloat16, 'kp'); _chk(vp, torch.bfloat16, 'vp')
     _chk(out, torch.bfloat16, 'out')
     if min(kp.numel(), vp.numel()) < packed_kv_numel(int(lk), int(heads)):
         raise lib.MoviigenHipError('packed K/V buffers too small for lk keys')
-    lib.call('mg_attn_fwd_bf16_hd128', _p(q), q.stride(0), _p(kp), _p(vp), _p(out), out.stride(0), q.shape[0],
-             int(lk), int(heads), float(scale), _st())
+    if prescaled:
+        lib.call('mg_attn_fwd_bf16_hd128_prescaled', _p(q), q.stride(0), _p(kp), _p(vp), _p(out), out.stride(0), None,
+                 q.shape[0], int(lk), int(heads), _st())
+    else:
+        lib.call('mg_attn_fwd_bf16_hd128', _p(q), q.stride(0), _p(kp), _p(vp), _p(out), out.stride(0), q.shape[0],
+                 int(lk), int(heads), float(scale), _st())
     return out
 
 
@@ -295,7 +304,7 @@ def image_to_u8(image, lo=-1.0, hi=1.0):
     return out
 
 
-def attention_hd128_lse(q, kp, vp, out, lse, lk, heads, scale):
+def attention_hd128_lse(q, kp, vp, out, lse, lk, heads, scale, prescaled=False):
     """attention_hd128 that also writes lse [heads, Lq] fp32 (log-sum-exp of the scaled scores)."""
     _chk(q, torch.bfloat16, 'q'); _chk(kp, torch.bfloat16, 'kp'); _chk(vp, torch.bfloat16, 'vp')
     _chk(out, torch.bfloat16, 'out'); _chk(lse, torch.float32, 'lse')
@@ -303,8 +312,12 @@ def attention_hd128_lse(q, kp, vp, out, lse, lk, heads, scale):
         raise lib.MoviigenHipError('packed K/V buffers too small for lk keys')
     if lse.numel() < int(heads) * q.shape[0] or not lse.is_contiguous():
         raise lib.MoviigenHipError('lse must be a contiguous [heads, Lq] fp32 tensor')
-    lib.call('mg_attn_fwd_bf16_hd128_lse', _p(q), q.stride(0), _p(kp), _p(vp), _p(out), out.stride(0), _p(lse),
-             q.shape[0], int(lk), int(heads), float(scale), _st())
+    if prescaled:
+        lib.call('mg_attn_fwd_bf16_hd128_prescaled', _p(q), q.stride(0), _p(kp), _p(vp), _p(out), out.stride(0), _p(lse),
+                 q.shape[0], int(lk), int(heads), _st())
+    else:
+        lib.call('mg_attn_fwd_bf16_hd128_lse', _p(q), q.stride(0), _p(kp), _p(vp), _p(out), out.stride(0), _p(lse),
+                 q.shape[0], int(lk), int(heads), float(scale), _st())
     return out, lse
 
 

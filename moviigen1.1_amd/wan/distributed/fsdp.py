@@ -92,7 +92,8 @@ class BlockShards:
         out = self.bufs[slot][:shard.numel() * self.P]
         from . import rccl_direct
         if shard.is_cuda and not self.staged and rccl_direct.enabled():
-            rccl_direct.comm_for(self.group).all_gather(out, shard)          # mg_shard_all_gather on the comm stream
+            # mg_shard_all_gather, enqueued on the CURRENT stream: _issue() calls this under `with stream(self.comm)`
+            rccl_direct.comm_for(self.group).shard_all_gather(out, shard)
         elif self.staged and shard.is_cuda:
             parts = [torch.empty(shard.shape, dtype=shard.dtype) for _ in range(self.P)]
             dist.all_gather(parts, shard.cpu(), group=self.group)

@@ -58,19 +58,40 @@ class DirectComm:
                  x.numel() * x.element_size(), self._st())
         return out
 
+    def shard_all_gather(self, full, shard):
+        """per-block parameter gather of the block-sharded weights (mg_shard_all_gather), on the CURRENT stream."""
+        assert full.is_contiguous() and shard.is_contiguous() and full.numel() == shard.numel() * self.size
+        lib.call('mg_shard_all_gather', self.handle, ctypes.c_void_p(shard.data_ptr()), ctypes.c_void_p(full.data_ptr()),
+                 shard.numel() * shard.element_size(), self._st())
+        return full
+
     def destroy(self):
         if self.handle:
             lib.call('mg_comm_destroy', self.handle)
             self.handle = None
 
 
-_COMMS = {}
+_COMMS = {}     # ProcessGroup object -> DirectComm (the dict holds the group, so the key cannot be recycled)
 
 
 def comm_for(group):
     """the DirectComm of a process group, created on first use (collectively: every rank of the group gets here at
-    the same point of the forward)."""
-    key = id(group) if group is not None else 0
-    if key not in _COMMS:
-        _COMMS[key] = DirectComm(group)
-    return _COMMS[key]
+    the same point of the forward).  None and dist.group.WORLD name the same ranks and share one communicator."""
+    group = group if group is not None else dist.group.WORLD
+    comm = _COMMS.get(group)
+    if comm is None:
+        if not _COMMS:
+            import atexit
+            atexit.register(destroy_all)
+        comm = _COMMS[group] = DirectComm(group)
+    return comm
+
+
+def destroy_all():
+    """ncclCommDestroy for every communicator created through comm_for (registered with atexit on first use)."""
+    for comm in list(_COMMS.values()):
+        try:
+            comm.destroy()
+        except Exception:       # the HIP runtime may already be gone at interpreter exit
+            pass
+    _COMMS.clear()

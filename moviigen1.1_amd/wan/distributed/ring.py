@@ -54,6 +54,8 @@ def enable_hybrid_sp(model, ulysses_size, ring_size, group=None):
     model.ring_group, model.ring_size, model.ring_rank = ring_groups[rank % U], R, rank // U
     model.ring = R > 1
     model._ws = {}
+    from .xdit_context_parallel import tag_attention_modules
+    tag_attention_modules(model)
     return model
 
 
@@ -73,8 +75,9 @@ def _exchange(send_bufs, recv_bufs, group, P, rank):
     return dist.batch_isend_irecv(reqs), None
 
 
-def ring_attention(q, k, v, out, ws, group, P, rank, heads, scale):
-    """q, k, v [Lloc, heads*128] bf16 (row strides free), out [Lloc, heads*128] bf16.
+def ring_attention(q, k, v, out, ws, group, P, rank, heads, scale, prescaled=False):
+    """q, k, v [Lloc, heads*128] bf16 (row strides free), out [Lloc, heads*128] bf16; prescaled: q already carries
+    scale*log2(e) (ops.rmsnorm_rope out_scale).
     ws: dict with packed buffers kp0/vp0/kp1/vp1, part (bf16 [Lloc, heads*128]), acc (fp32), lse, lse_acc."""
     Lloc = q.shape[0]
     cur, nxt = (ws['kp0'], ws['vp0']), (ws['kp1'], ws['vp1'])
@@ -83,7 +86,7 @@ def ring_attention(q, k, v, out, ws, group, P, rank, heads, scale):
         pending = None
         if j + 1 < P:
             pending = _exchange(list(cur), list(nxt), group, P, rank)
-        ops.attention_hd128_lse(q, cur[0], cur[1], ws['part'], ws['lse'], Lloc, heads, scale)
+        ops.attention_hd128_lse(q, cur[0], cur[1], ws['part'], ws['lse'], Lloc, heads, scale, prescaled=prescaled)
         ops.attention_merge(ws['acc'], ws['lse_acc'], ws['part'], ws['lse'], heads, first=(j == 0),
                             out=out if j == P - 1 else None)
         if pending is not None:

@@ -62,7 +62,34 @@ def split_heads(n_loc, max_groups):
 
 class HeadExchange:
     """persistent buffers, events and the communication stream of the pipelined exchange for one
-    (group, Lloc) shape.  `run(q, k, v, out, attend)` executes one layer's exchange + attention."""
+    (group, Lloc) shape.  `run(q, k, v, out, attend)` executes one layer's exchange + attention.
+
+    Measurement hook (bench.py): while `HeadExchange.trace` is a list, every collective is bracketed by timing events
+    on the comm stream and every wait of the compute stream on the comm stream by timing events on the compute
+    stream; `overlap_summary()` turns them into (exchange time, time the compute stream stood waiting for it)."""
+
+    trace = None        # None = off; a list = collect (kind, start event, end event)
+
+    @classmethod
+    def _mark(cls, kind, stream):
+        if cls.trace is None:
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(stream)
+        cls.trace.append((kind, ev))
+        return ev
+
+    @classmethod
+    def overlap_summary(cls):
+        """-> dict(exchange_ms, exposed_ms, hidden_frac) over everything traced so far (call after a device sync)."""
+        tr = cls.trace or []
+        tot = {'comm': 0.0, 'wait': 0.0}
+        for i in range(0, len(tr) - 1, 2):
+            (k0, a), (k1, b) = tr[i], tr[i + 1]
+            assert k0 == k1
+            tot[k0] += a.elapsed_time(b)
+        hidden = 1.0 - tot['wait'] / tot['comm'] if tot['comm'] > 0 else None
+        return {'exchange_ms': tot['comm'], 'exposed_ms': tot['wait'], 'hidden_frac': hidden, 'collectives': len(tr) // 4}
 
     def __init__(self, group, P, heads, head_dim, Lloc, device, max_groups=None):
         if heads % P:
@@ -97,20 +124,28 @@ class HeadExchange:
         with torch.cuda.stream(self.comm):
             for g in range(len(self.groups)):
                 self.comm.wait_event(self.ev_pack[g])
+                self._mark('comm', self.comm)
                 _a2a(self.recv[g].view(P, self.Lloc, -1), self.send[g], self.group)
+                self._mark('comm', self.comm)
                 self.ev_recv[g].record(self.comm)
         for g, (h0, n) in enumerate(self.groups):
             w = n * hd
+            self._mark('wait', cur)
             cur.wait_event(self.ev_recv[g])
+            self._mark('wait', cur)
             r = self.recv[g]
             attend(r[:, :w], r[:, w:2 * w], r[:, 2 * w:], self.ag[g], n)
             self.ev_attn[g].record(cur)
             with torch.cuda.stream(self.comm):
                 self.comm.wait_event(self.ev_attn[g])
+                self._mark('comm', self.comm)
                 _a2a(self.orecv[g], self.ag[g].view(P, self.Lloc, w), self.group)
+                self._mark('comm', self.comm)
                 self.ev_o[g].record(self.comm)
         for g, (h0, n) in enumerate(self.groups):
+            self._mark('wait', cur)
             cur.wait_event(self.ev_o[g])
+            self._mark('wait', cur)
             ops.sp_unpack_o(self.orecv[g], P, self.cols, h0 * hd, n * hd, out)
         return out
 

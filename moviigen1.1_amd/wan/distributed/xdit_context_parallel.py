@@ -26,6 +26,21 @@ def enable_sequence_parallel(model, group=None):
     model.sp_rank = dist.get_rank(group)
     model.ring, model.uly_group, model.uly_size, model.ring_group, model.ring_size = False, None, None, None, None
     model._ws = {}
+    tag_attention_modules(model)
+    return model
+
+
+def tag_attention_modules(model):
+    """record on every self-attention module WHICH ranks its stand-alone operator (usp_attn_forward) exchanges with:
+    the model's Ulysses group, its size and this rank's index in it — the CFG-parallel halves, the training-side
+    sub-groups and the hybrid layout's inner groups all differ from WORLD."""
+    U, R = model._sp_layout()
+    group = model.uly_group if model.uly_group is not None else model.sp_group
+    for blk in model.blocks:
+        if R > 1:       # ring / hybrid layouts: K/V blocks travel between the groups — only the fused forward does that
+            blk.self_attn.sp = 'ring'
+        else:           # (group, size, rank inside the group, rank that sets the RoPE position offset)
+            blk.self_attn.sp = (group, U, model.sp_rank % U, model.sp_rank) if U > 1 else None
     return model
 
 
@@ -41,7 +56,7 @@ def usp_attn_forward(self, x, seq_lens, grid_sizes, freqs, dtype=None):
     all tokens x heads/P, all-to-all back, output projection.  Installing it with
     `types.MethodType(usp_attn_forward, block.self_attn)` (reference text2video.py:97-100) is honoured: WanModel.forward
     recognises it and keeps its fused, pipelined implementation of exactly this operator."""
-    sp = None
-    if dist.is_initialized() and dist.get_world_size() > 1:
-        sp = (dist.group.WORLD, dist.get_world_size(), dist.get_rank())
+    sp = getattr(self, 'sp', None)      # set by enable_sequence_parallel / enable_cfg_parallel / enable_hybrid_sp
+    if sp is None and not hasattr(self, 'sp') and dist.is_initialized() and dist.get_world_size() > 1:
+        sp = (dist.group.WORLD, dist.get_world_size(), dist.get_rank(), dist.get_rank())   # never configured: the reference's default
     return type(self).forward(self, x, seq_lens, grid_sizes, freqs, sp=sp)

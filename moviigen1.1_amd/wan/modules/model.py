@@ -8,7 +8,7 @@ reference checkpoint layout: config.json + diffusion_pytorch_model*.safetensors)
 What differs is HOW a forward runs.  The reference composes ~40 torch ops per block under
 autocast; here a block is 14 kernel launches from libmoviigen_hip.so:
 
-    ln_modulate -> gemm(QKV fused, N=3*dim) -> rmsnorm_rope(q) / rmsnorm_rope(k) / pack_kv
+    ln_modulate -> gemm(QKV fused, N=3*dim) -> rmsnorm_rope(q, x softmax_scale*log2e) / rmsnorm_rope(k) / pack_kv
     -> attention -> gemm(o) with `x += y*gate` fused  -> ln_modulate(norm3 affine) -> gemm(q)
     -> rmsnorm -> attention(512 cached text keys) -> gemm(o) with `x += y` fused
     -> ln_modulate -> gemm(ffn.0)+GELU fused -> gemm(ffn.2) with `x += y*gate` fused
@@ -67,12 +67,16 @@ class _Attn(nn.Module):
         self.norm_q = _Vec(dim, device)
         self.norm_k = _Vec(dim, device)
         self.dim, self.num_heads, self.eps = dim, num_heads, eps
+        self._xchg = {}     # (group, Lloc, device) -> HeadExchange of the stand-alone sequence-parallel operator
 
     def forward(self, x, seq_lens, grid_sizes, freqs=None, sp=None):
         """WanSelfAttention.forward (model.py:127-156): x [B, L, C] -> [B, L, C] bf16.  `freqs` (the reference's
         complex table) is accepted and ignored: the rotation angles are rebuilt from grid_sizes (same formula).
-        sp = (group, size, rank): x is the rank's token shard, Ulysses exchange around the attention
-        (usp_attn_forward, xdit_context_parallel.py:155-198)."""
+        sp = (group, size, rank in the group, rank of the token shard): x is the rank's token shard, Ulysses exchange
+        around the attention (usp_attn_forward, xdit_context_parallel.py:155-198)."""
+        if sp == 'ring':
+            raise NotImplementedError('the stand-alone self-attention operator does not rotate K/V blocks: under the ring / '
+                                      'hybrid layouts call WanModel.forward (wan/distributed/ring.py)')
         d, N = self.dim, self.num_heads
         hd = d // N
         scale = 1.0 / math.sqrt(hd)
@@ -86,10 +90,15 @@ class _Attn(nn.Module):
             q, k, v = (torch.empty(L, d, dtype=bf, device=dev) for _ in range(3))
             for lin, dst in ((self.q, q), (self.k, k), (self.v, v)):
                 ops.gemm(h, lin.weight, lin.bias, ops.BIAS_BF16, dst)
-            P, rank = (sp[1], sp[2]) if sp else (1, 0)
+            P = sp[1] if sp else 1
+            pos_rank = (sp[3] if len(sp) > 3 else sp[2]) if sp else 0
             qn, kn = torch.empty_like(q), torch.empty_like(k)
-            ops.rmsnorm_rope(q, self.norm_q.weight, self.eps, hd, qn, rope, grid, rank * L)
-            ops.rmsnorm_rope(k, self.norm_k.weight, self.eps, hd, kn, rope, grid, rank * L)
+            # head_dim 128: softmax_scale * log2(e) folded into q before its one rounding to bf16, exactly as the fused
+            # layer loop does (WanModel._q_scale): the stand-alone operator and the fused one give the same bits
+            pre = hd == 128
+            ops.rmsnorm_rope(q, self.norm_q.weight, self.eps, hd, qn, rope, grid, pos_rank * L,
+                             out_scale=scale * ops.ATTN_LOG2E if pre else 1.0)
+            ops.rmsnorm_rope(k, self.norm_k.weight, self.eps, hd, kn, rope, grid, pos_rank * L)
             a = torch.empty(L, d, dtype=bf, device=dev)
 
             def attend(qg, kg, vg, ag, heads, klen):
@@ -97,12 +106,16 @@ class _Attn(nn.Module):
                     n_pk = ops.packed_kv_numel(klen, heads)
                     kp, vp = torch.empty(n_pk, dtype=bf, device=dev), torch.empty(n_pk, dtype=bf, device=dev)
                     ops.pack_kv(kg[:klen], vg[:klen], heads, kp, vp)
-                    ops.attention_hd128(qg, kp, vp, ag, klen, heads, scale)
+                    ops.attention_hd128(qg, kp, vp, ag, klen, heads, scale, prescaled=pre)
                 else:
                     ops.attention_generic(qg, kg, vg, ag, klen, heads, hd, scale)
             if P > 1:
                 from ..distributed.ulysses import HeadExchange
-                ex = HeadExchange(sp[0], P, N, hd, L, dev)
+                key = (sp[0], L, str(dev))
+                ex = self._xchg.get(key)
+                if ex is None:          # one live shape: the buffers and the stream are persistent, not per call
+                    self._xchg = {key: HeadExchange(sp[0], P, N, hd, L, dev)}
+                    ex = self._xchg[key]
                 ex.run(qn, kn, v, a, lambda qg, kg, vg, ag, n: attend(qg, kg, vg, ag, n, kg.shape[0]))
             else:
                 klen = min(L, int(seq_lens[b])) if seq_lens is not None else L
@@ -429,12 +442,19 @@ class WanModel(nn.Module):
         return kc, kv[:, d:].clone()
 
     # ------------------------------------------------------------------------------------------
+    def _q_scale(self):
+        """factor the fused forward folds into q when it is RMS-normed (ops.rmsnorm_rope out_scale): the attention's
+        softmax_scale * log2(e) for the head_dim 128 kernel — q is rounded to bf16 once either way, and the kernel then
+        needs no per-score multiply (flash_attn applies softmax_scale to the fp32 scores: same product) — else 1."""
+        hd = self.dim // self.num_heads
+        return ops.ATTN_LOG2E / math.sqrt(hd) if hd == 128 else 1.0
+
     def _attention(self, q, k, v, out, lk, heads):
-        """head_dim 128: k, v are PACKED tile buffers (ops.pack_kv); otherwise row-major."""
+        """head_dim 128: q PRE-SCALED (_q_scale), k, v PACKED tile buffers (ops.pack_kv); otherwise row-major."""
         hd = self.dim // self.num_heads
         scale = 1.0 / math.sqrt(hd)
         if hd == 128:
-            ops.attention_hd128(q, k, v, out, lk, heads, scale)
+            ops.attention_hd128(q, k, v, out, lk, heads, scale, prescaled=True)
         else:
             ops.attention_generic(q, k, v, out, lk, heads, hd, scale)
 
@@ -443,7 +463,7 @@ class WanModel(nn.Module):
         d, hd, N = self.dim, self.dim // self.num_heads, self.num_heads
         qkv = ws['qkv']
         sa = blk.self_attn
-        ops.rmsnorm_rope(qkv[:, :d], sa.norm_q.weight, self.eps, hd, ws['q'], rope, grid, pos0)
+        ops.rmsnorm_rope(qkv[:, :d], sa.norm_q.weight, self.eps, hd, ws['q'], rope, grid, pos0, out_scale=self._q_scale())
         ops.rmsnorm_rope(qkv[:, d:2 * d], sa.norm_k.weight, self.eps, hd, ws['k'], rope, grid, pos0)
         if self.sp_size == 1 and not self.sp_force:
             if hd == 128:
@@ -462,11 +482,11 @@ class WanModel(nn.Module):
         def attend(qg, kg, vg, ag, heads):      # operands may be strided column views; ag contiguous
             if R > 1:                           # ring attention across the groups (hd 128 only)
                 from ..distributed.ring import ring_attention
-                ring_attention(qg, kg, vg, ag, ws, rg, R, rr, heads, scale)
+                ring_attention(qg, kg, vg, ag, ws, rg, R, rr, heads, scale, prescaled=True)
             elif hd == 128:
                 kv = min(kg.shape[0], self._kv_valid)       # keys past the video's tokens are padding (k_lens)
                 ops.pack_kv(kg[:kv], vg[:kv], heads, ws['kp'], ws['vp'])
-                ops.attention_hd128(qg, ws['kp'], ws['vp'], ag, kv, heads, scale)
+                ops.attention_hd128(qg, ws['kp'], ws['vp'], ag, kv, heads, scale, prescaled=True)
             else:
                 ops.attention_generic(qg, kg, vg, ag, min(kg.shape[0], self._kv_valid), heads, hd, scale)
 
@@ -578,7 +598,7 @@ class WanModel(nn.Module):
             kc, vc = ctx_layers[i]
             ops.ln_modulate(x, blk.norm3.weight, blk.norm3.bias, False, eps, ws['h'])
             ops.gemm(ws['h'], lw['cross_attn.q'], ca.q.bias, ops.BIAS_BF16, ws['q'])
-            ops.rmsnorm_rope(ws['q'], ca.norm_q.weight, eps, d // self.num_heads, ws['k'])
+            ops.rmsnorm_rope(ws['q'], ca.norm_q.weight, eps, d // self.num_heads, ws['k'], out_scale=self._q_scale())
             if self.cross_attn_head_sharded and P > 1:
                 self._cross_attention_head_sharded(ws, kc, vc)
             else:

@@ -85,6 +85,8 @@ class WanModel(_EngineWanModel):
         elif want == 1 and self.sp_size != 1:
             self.sp_size, self.sp_rank, self.sp_group = 1, 0, None
             self._ws = {}
+            for blk in self.blocks:
+                blk.self_attn.sp = None
         self.sp_mask_padded_keys = True        # pad to seq_len, chunk, mask the padded keys (:704-706, :757, :247-252)
         self.cross_attn_head_sharded = True    # :271-294
 

@@ -47,5 +47,5 @@ def _reset_kernel_selection(request):
     if h is not None:
         h.mg_attn_set_variant(lib.DEFAULT_ATTN_VARIANT)
         h.mg_gemm_set_variant(lib.DEFAULT_GEMM_VARIANT)
-        h.mg_attn_set_lazy_rescale(1)
         h.mg_attn_w64_debug(0)
+        h.mg_attn_w64_flag_counter(None)

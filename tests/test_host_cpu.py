@@ -26,7 +26,7 @@ def test_cabi_exports_every_declared_symbol():
     handle = lib.load()
     for name in declared:
         assert hasattr(handle, name), name
-    assert handle.mg_abi_version() == 3
+    assert handle.mg_abi_version() == 4
     assert b'gfx950' in handle.mg_version()
     # and nothing undeclared leaks out of the .so: every exported mg_* symbol is in the header
     import subprocess
@@ -269,3 +269,24 @@ def test_bench_flop_formulas():
     assert abs(tot / 1e12 - 1116.5) < 0.1 and abs(attn / 1e12 - 20.1) < 0.05
     assert abs(b.vae_decode_flops(21, 90, 160)[0] / 1e12 - 639.2) < 0.1
     assert b.WORKLOADS['1080p'][:3] == (1920, 832, 81)
+
+
+def test_bench_self_launch_command():
+    """`python bench.py --gpus N` without WORLD_SIZE becomes the launcher of its own ranks (reference launch contract
+    scripts/inference/generate.py:190-229: one process per GPU): the command it re-executes, checked without running it."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    env['MOVIIGEN_BENCH_DRYRUN'] = '1'
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '3', '--warmup', '1'],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    cmd = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][0])['launch']
+    assert cmd[1:4] == ['-m', 'torch.distributed.run', '--nnodes=1'] and '--nproc-per-node=8' in cmd
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and int(cmd[cmd.index('--master-port') + 1]) > 0
+    i = cmd.index(os.path.join(ROOT, 'bench.py'))
+    assert cmd[i + 1:] == ['--gpus', '8', '--steps', '3', '--warmup', '1']
+    # under a launcher (WORLD_SIZE set) nothing is re-executed: the dry-run marker is not printed, the rank path runs
+    # (and stops at the missing GPU here)
+    env2 = dict(env, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '1', '--workload', 'tiny'],
+                        capture_output=True, text=True, timeout=300, env=env2)
+    assert '"launch"' not in r2.stdout

@@ -2,7 +2,7 @@
 # One-shot GPU verification used at the end of a round: parity tests, smoke, bench (the metric's 1920x832x81f
 # workload), rocprof stats of the same command, HBM-traffic PMC passes of the dominant kernel.
 # usage: tools/round_end_gpu.sh <tag> [workload]      (PMC passes use --layers 4: per-launch traffic is layer-independent)
-TAG=${1:-r02}
+TAG=${1:-r03}
 WL=${2:-1080p}
 R=$PWD; mkdir -p gpurun_out
 if [ -z "$SKIP_PYTEST" ]; then
@@ -29,14 +29,14 @@ for tag, name in (('fetch', 'FETCH_SIZE'), ('write', 'WRITE_SIZE')):
 PY
 python3 tools/rocprof_summary.py $(ls gpurun_out/${TAG}_prof/*/*_results.db gpurun_out/${TAG}_prof/*_results.db 2>/dev/null | head -1) gpurun_out/${TAG}_bench${WL}_kernel_stats.txt > /dev/null 2>&1
 python3 - <<PY
-# HBM-side traffic of the dominant kernel (self-attention = the long dispatches of attn_hd128_w64_kernel), per launch
+# HBM-side traffic of the dominant kernel (self-attention = the long dispatches of attn_hd128_m16_kernel), per launch
 import csv, glob, json
 L = {'720p': 75600, '1080p': 131040, '1056p': 166320}.get('${WL}', 0)
 def mean_kib(tag):
     v = []
     for f in glob.glob('gpurun_out/${TAG}_pmc_%s/**/*counter_collection.csv' % tag, recursive=True):
         for r in csv.DictReader(open(f)):
-            if 'attn_hd128_w64_kernel' in r['Kernel_Name']:
+            if 'attn_hd128_m16_kernel' in r['Kernel_Name']:
                 v.append(float(r['Counter_Value']))
     if v and max(v) > 4 * min(v):      # the same kernel also serves the 512-key cross-attention: keep the long launches
         cut = (max(v) + min(v)) / 2
@@ -44,7 +44,7 @@ def mean_kib(tag):
     return (sum(v) / len(v), len(v)) if v else (None, 0)
 fe, nf = mean_kib('fetch'); wr, nw = mean_kib('write')
 if fe is not None and wr is not None:
-    out = {'kernel': 'attn_hd128_w64_kernel, self-attention Lq=Lk=%d, 40 heads (bench.py ${WL} workload)' % L,
+    out = {'kernel': 'attn_hd128_m16_kernel, self-attention Lq=Lk=%d, 40 heads (bench.py ${WL} workload)' % L,
            'method': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, two separate passes of bench.py --workload ${WL} --layers 4 --steps 1 --warmup 0 (tools/round_end_gpu.sh; the launch shape does not depend on the layer count); mean over the dispatches of the kernel',
            'dispatches': [nf, nw], 'fetch_size_kib_per_launch_raw': fe, 'write_size_kib_per_launch_raw': wr,
            'gfx950_correction': 'FETCH_SIZE reports 1/2 of the bytes of a wide coalesced read stream (MI355X_MICROARCH.md, HBM section): doubled; WRITE_SIZE as is',
