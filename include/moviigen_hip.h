@@ -306,7 +306,8 @@ int mg_t5_attn_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v, int
  * are zero before that (CausalConv3d, wan/modules/vae.py:17-36).  Spatial zero padding
  * (kh/2, kw/2).  `up2`: the input is read through a nearest-exact 2x upsample (Ho=2H, Wo=2W;
  * Resample upsample2d/3d, vae.py:66-83,138-141).  residual (same shape as out, may be NULL) is
- * added (ResidualBlock `x + h`, vae.py:220). */
+ * added (ResidualBlock `x + h`, vae.py:220).  kt <= 3, kh and kw in {1, 3} (what WanVAE uses); larger extents return
+ * MG_ERR_SHAPE. */
 int mg_vae_conv_f32(const float* x, const float* cache, int tc, int T, int H, int W, int Cin,
                     const float* w, const float* bias, int Cout, int kt, int kh, int kw, int up2,
                     const float* residual, float* out, void* stream);

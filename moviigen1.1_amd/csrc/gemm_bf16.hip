@@ -138,6 +138,8 @@ int mg_gemm_v5_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_
                       int N, int K, int epilogue, void* out, int64_t ldo, const float* gate, hipStream_t st);
 int mg_gemm_v6_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_t ldw, const float* bias, int64_t M,
                       int N, int K, int epilogue, void* out, int64_t ldo, const float* gate, hipStream_t st);
+int mg_gemm_v7_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_t ldw, const float* bias, int64_t M,
+                      int N, int K, int epilogue, void* out, int64_t ldo, const float* gate, hipStream_t st);
 int mg_gemm_v2_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_t ldw, const float* bias, int64_t M,
                       int N, int K, int epilogue, void* out, int64_t ldo, const float* gate, hipStream_t st);
 
@@ -145,6 +147,8 @@ int mg_gemm_v2_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_
 // one per SIMD (gemm_bf16_v5.hip).  (3, the 8-wave 256x256 tile, was an A/B partner only: experiments/gemm_bf16_v3_8waves.hip.)
 // Process-global and NOT thread-safe on purpose: a measurement / test switch (tools/, tests/conftest.py resets it after
 // every test), never touched by the product path — mg_gemm_bf16 itself picks by shape.
+unsigned long long* g_gemm5_prof = nullptr;   // debug hook of the 256x256 kernels (variants 5 and 7): 4 waves x {wait+barrier, first half, second half, k-tiles}
+extern "C" void mg_gemm5_debug_profile(unsigned long long* dev_buf) { g_gemm5_prof = dev_buf; }
 static int g_gemm_variant = 0;   // 0 = by shape AND epilogue (below)
 extern "C" void mg_gemm_set_variant(int v) { g_gemm_variant = v; }
 
@@ -158,10 +162,11 @@ extern "C" int mg_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* Wt, 
     if (bias && ((uintptr_t)bias & 15)) return MG_ERR_SHAPE;
     if (gate && ((uintptr_t)gate & 15)) return MG_ERR_SHAPE;
     if (M == 0) return MG_OK;
-    // default: the persistent loop (6) wins where the epilogue only stores (r02c, M = 131 040: +1.8 % q|k|v, +3.3 % ffn.0,
-    // +1.7 % cross q) and loses 1.5 % on the residual epilogue, whose read-modify-write of x competes with the
-    // prefetch of the next tile — that one keeps one tile per workgroup (5)
-    const int variant = g_gemm_variant ? g_gemm_variant : (epilogue == MG_EPI_GATE_RESID_F32 ? 5 : 6);
+    // default: variant 7, the persistent 256x256 loop on 16x16x32 MFMAs (profiles/r03d_gemmshapes_*: +1.6 % q|k|v,
+    // +3.8 % self-attn o, +4 % cross q, +0 % ffn.0, +1.7 % ffn.2 over the better of 5 / 6 at M = 131 040)
+    const int variant = g_gemm_variant ? g_gemm_variant : 7;
+    if (variant == 7 && M > 256 && N > 128)
+        return mg_gemm_v7_launch(A, lda, Wt, ldw, bias, M, N, K, epilogue, out, ldo, gate, (hipStream_t)stream);
     if (variant == 6 && M > 256 && N > 128)
         return mg_gemm_v6_launch(A, lda, Wt, ldw, bias, M, N, K, epilogue, out, ldo, gate, (hipStream_t)stream);
     if (variant == 5 && M > 256 && N > 128)

@@ -22,8 +22,7 @@ typedef const __attribute__((address_space(1))) void* v5_gptr_t;
 typedef __attribute__((address_space(3))) void* v5_lptr_t;
 MG_DEV void v5_glds16(const void* g, void* l) { __builtin_amdgcn_global_load_lds((v5_gptr_t)g, (v5_lptr_t)l, 16, 0, 0); }
 
-static unsigned long long* g_gemm5_prof = nullptr;
-extern "C" void mg_gemm5_debug_profile(unsigned long long* dev_buf) { g_gemm5_prof = dev_buf; }
+extern unsigned long long* g_gemm5_prof;    // gemm_bf16.hip: mg_gemm5_debug_profile (shared by the 256x256 kernels)
 
 // hand-issued fragment reads (base VGPR + immediate) with counted waits: hipcc guards a register ring of plain
 // LDS loads with `s_waitcnt lgkmcnt(0)` at every k-step boundary, i.e. it waits for the read it issued last

@@ -291,6 +291,9 @@ extern "C" int mg_vae_conv_f32(const float* x, const float* cache, int tc, int T
     if (T <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 3) || Cout <= 0 || kt < 1 || kh < 1 || kw < 1 ||
         !(kh & 1) || !(kw & 1) || tc < 0 || tc > kt - 1 || (tc > 0 && !cache))
         return MG_ERR_SHAPE;
+    // the tile gather keeps one validity bit per tap offset and axis in 3-bit fields: extents above 3 would alias
+    // (WanVAE uses 1 and 3 only, reference vae.py:17-36)
+    if (kt > 3 || kh > 3 || kw > 3) return MG_ERR_SHAPE;
     if (((uintptr_t)x & 15) || ((uintptr_t)w & 15) || ((uintptr_t)out & 15) || (cache && ((uintptr_t)cache & 15)) ||
         (bias && ((uintptr_t)bias & 15)) || (residual && ((uintptr_t)residual & 15)))
         return MG_ERR_SHAPE;

@@ -295,6 +295,17 @@ class WanVAE:
     def decode(self, zs):
         return [self.model.decode(u) for u in zs]
 
+    def decode_peak_bytes(self, latent_shape):
+        """upper bound of the device memory a decode of a [16, T, h, w] latent needs at its peak: the video itself
+        plus, per decoder call of 4 latent frames, a handful of live fp32 activations of the widest stage (96 channels
+        at 8h x 8w, 16 output frames; measured peak at 1920x832x81f: 45 GB) — used by WanT2V.generate to decide whether
+        `offload_model` has to move anything."""
+        _, T, h, w = latent_shape
+        frames = 1 + 4 * (T - 1)
+        video = 3 * frames * 64 * h * w * 4
+        act = 16 * 64 * h * w * 96 * 4          # one [16 frames, 8h, 8w, 96] fp32 activation
+        return video + 8 * act
+
     def decode_pipelined(self, zs, group=None):
         """multi-GPU decode: every rank calls it with the same latents; videos on rank 0, None elsewhere."""
         return [self.model.decode_pipelined(u, group) for u in zs]

@@ -140,7 +140,8 @@ class WanT2V:
 
             latent = noise
             timesteps_host = timesteps.tolist()          # ONE sync for the whole loop
-            self.model.to(self.device)
+            if next(self.model.parameters()).device != self.device:     # only after a real offload (a no-op move would
+                self.model.to(self.device)                               # still drop the fused-weight views: 28 GB re-packed)
             noise_pred = torch.empty_like(latent)
             for i, t_host in enumerate(timesteps_host):
                 t = timesteps[i:i + 1]
@@ -157,9 +158,24 @@ class WanT2V:
                 if callback is not None:
                     callback(i, latent)
             x0 = [latent]
+            offloaded = False
             if offload_model:
-                self.model.cpu()
+                # reference text2video.py:257-259 moves the DiT to the host before the VAE decode to make room on an
+                # 80 GB device.  Here that is 28 GB over PCIe and back on the next call, for nothing, whenever the decode
+                # fits beside the resident model — which it does on 288 GB: the flag then only drops the DiT's activation
+                # workspace; the weights move only when the free memory would not hold the decode's peak.
+                self.model._ws = {}
                 torch.cuda.empty_cache()
+                free_b, _ = torch.cuda.mem_get_info(self.device)
+                need_b = self.vae.decode_peak_bytes(target_shape) if hasattr(self.vae, 'decode_peak_bytes') else 32 << 30
+                if free_b > need_b:
+                    logging.info(f'offload_model: {free_b / 2**30:.0f} GiB free >= {need_b / 2**30:.0f} GiB for the VAE decode '
+                                 '-> the DiT stays resident (nothing is moved to the host)')
+                else:
+                    self.model.cpu()
+                    torch.cuda.empty_cache()
+                    offloaded = True
+            self.last_offloaded = offloaded
             if self.vae_parallel:    # layer-pipelined decode over all ranks, video assembled on rank 0
                 videos = self.vae.decode_pipelined(x0)
                 videos = videos if self.rank == 0 else None

@@ -137,7 +137,7 @@ def test_gemm_tile_variants_agree(dev, M, N, K):
     b = W.randn((N,), 18).to(dev)
     outs = []
     try:
-        for v in (0, 1, 2, 5, 6):
+        for v in (0, 1, 2, 5, 6, 7):
             lib.load().mg_gemm_set_variant(v)
             o = torch.full((M + 1, N), -7.0, dtype=torch.float32, device=dev)      # guard row: no write past M
             ops.gemm(a, w, b, ops.BIAS_F32, o[:M])
@@ -777,6 +777,17 @@ def test_vae_conv_shapes(dev, cin, cout, T, H, W, tc, up2):
     assert ((got - ref).abs().max() / ref.abs().max()).item() < 1e-5
 
 
+def test_vae_conv_rejects_large_kernel_extents(dev):
+    """the tile gather's per-tap validity masks hold extents up to 3: a 5x5 (or 5-frame) kernel is refused, not mis-computed."""
+    from wan.backend import lib, ops
+    x = torch.zeros(2, 8, 8, 32, device=dev)
+    out = torch.empty(2, 8, 8, 32, device=dev)
+    for (kt, kh, kw) in ((1, 5, 5), (5, 3, 3), (3, 3, 5)):
+        w = torch.zeros(32, kt, kh, kw, 32, device=dev)
+        with pytest.raises(lib.MoviigenHipError):
+            ops.vae_conv(x, w, None, out, kt, kh, kw)
+
+
 def test_fullsize_vae_decode_config5(dev):
     """BASELINE configs[4]: the 1920x832x81f decode (latent [16,21,104,240], seed 7) through WanVAE.decode:
     shape / finite / range, and two size-independent properties of the causal decoder — the first 17 output frames
@@ -1083,6 +1094,68 @@ def test_bench_multirank_code_path(world, extra, plain):
         assert ov['exchange_ms_per_step'] > 0 and ov['exposed_ms_per_step'] >= 0 and ov['hidden_frac'] <= 1.0
     else:
         assert d['overlap'] is None
+
+
+def test_fullsize_generate_call(dev):
+    """ONE call through the drop-in surface at the metric's size (reference wan/text2video.py:158-271): WanT2V.generate
+    on the 14B architecture (random weights), 1920x832x81f, 2 UniPC steps, dim-96 WanVAE decode — shape / range /
+    finite, the per-step latents equal to a hand-driven loop over the same WanModel (what bench.py times), the same
+    video again under offload_model=True (a no-op on 288 GB: the DiT must stay on the device), and the wall time of
+    the call against steps x step + decode."""
+    import time
+    import wan
+    from wan.backend import ops
+    from wan.configs import WAN_CONFIGS
+    from wan.utils import FlowUniPCMultistepScheduler
+    cfg = WAN_CONFIGS['t2v-14B']
+    model = wan.modules.WanModel(dim=cfg.dim, ffn_dim=cfg.ffn_dim, freq_dim=cfg.freq_dim, num_heads=cfg.num_heads,
+                                 num_layers=cfg.num_layers, text_len=cfg.text_len, eps=cfg.eps, device=dev)
+    model.init_weights(seed=0)
+    vae = wan.modules.WanVAE(state_dict=W.make_vae_params(96, 1), device=dev)
+    g = torch.Generator(device=dev).manual_seed(5)
+    ctx = torch.randn(512, 4096, device=dev, generator=g).bfloat16()
+    ctx_null = torch.randn(130, 4096, device=dev, generator=g).bfloat16()
+    pipe = wan.WanT2V(cfg, checkpoint_dir=None, model=model, vae=vae)
+    lats = []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    video = pipe.generate(ctx, size=(1920, 832), frame_num=81, sampling_steps=2, n_prompt=ctx_null, seed=11,
+                          offload_model=False, callback=lambda i, lat: lats.append(lat.clone()))
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    assert tuple(video.shape) == (3, 81, 832, 1920) and video.dtype == torch.float32
+    assert torch.isfinite(video).all().item() and video.abs().max().item() <= 1.0
+    assert len(lats) == 2 and tuple(lats[0].shape) == (16, 21, 104, 240)
+    # the same two steps driven by hand (bench.py's loop): identical latents
+    noise = torch.randn(16, 21, 104, 240, dtype=torch.float32, device=dev, generator=torch.Generator(device=dev).manual_seed(11))
+    sch = FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)
+    sch.set_timesteps(2, device=dev, shift=5.0)
+    lat, pred = noise, torch.empty_like(noise)
+    L = 21 * 52 * 120
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for i, th in enumerate(sch.timesteps.tolist()):
+        t = sch.timesteps[i:i + 1]
+        c = model([lat], t=t, context=[ctx], seq_len=L)[0]
+        u = model([lat], t=t, context=[ctx_null], seq_len=L)[0]
+        ops.cfg_combine(pred, u, c, 5.0)
+        lat = sch.step(pred.unsqueeze(0), th, lat.unsqueeze(0), return_dict=False)[0].squeeze(0)
+        assert torch.equal(lat, lats[i]), i
+    torch.cuda.synchronize()
+    loop_s = time.perf_counter() - t1
+    t2 = time.perf_counter()
+    video2 = vae.decode([lat])[0]
+    torch.cuda.synchronize()
+    dec_s = time.perf_counter() - t2
+    assert torch.equal(video2, video)
+    # no hidden cost in the call: its wall time is the loop + the decode (+ scheduler set-up, noise, < 3 %)
+    assert wall < 1.03 * (loop_s + dec_s) + 0.5, (wall, loop_s, dec_s)
+    print(f'generate(1920x832x81f, 2 steps): {wall:.2f} s = loop {loop_s:.2f} s + decode {dec_s:.2f} s')
+    # offload_model=True (the reference default): nothing has to move on this device, same bits
+    del video2
+    video3 = pipe.generate(ctx, size=(1920, 832), frame_num=81, sampling_steps=2, n_prompt=ctx_null, seed=11, offload_model=True)
+    assert pipe.last_offloaded is False and next(model.parameters()).is_cuda
+    assert torch.equal(video3, video)
 
 
 def test_bench_refuses_more_ranks_than_gpus():

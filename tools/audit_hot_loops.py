@@ -1,0 +1,87 @@
+"""Static audit of the MFMA hot loops: compile a kernel source to gfx950 assembly and check, for every instantiation of
+the named kernel, the basic block that holds its steady-state loop (the block with the most MFMAs):
+
+  * no scratch access and no v_cndmask / v_readfirstlane chains in it (a runtime-indexed register array — e.g. a
+    pointer array indexed by a value hipcc did not fold — turns into hundreds of selects per iteration: the round-3
+    GEMM ran 7x slower in ONE epilogue instantiation that way, with every parity test green),
+  * the expected MFMA count, and at most `max_other` other instructions.
+
+usage: python tools/audit_hot_loops.py            (exit code 1 on a violation; prints one line per kernel)
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, 'moviigen1.1_amd', 'csrc')
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+
+# source file, kernel name fragment, regex of instantiations to skip (the s_memtime profiling builds), MFMAs per
+# iteration, max other instructions per iteration
+KERNELS = [
+    ('gemm_bf16_v7.hip', 'gemm_bf16_v7_kernel', r'kernelILi\dELb1E', 128, 180),
+    ('attn_hd128_m16.hip', 'attn_hd128_m16_kernel', r'kernelILb1E', 128, 330),
+]
+FORBIDDEN = ('scratch_', 'v_cndmask', 'v_readfirstlane')
+MAX_ACC_MOVES = 8      # v_accvgpr_read / _write per iteration (register-file shuffles of a kernel at the 512-register limit)
+
+
+def device_asm(src):
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, 'k.s')
+        subprocess.run([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '--cuda-device-only', '-S', os.path.join(CSRC, src),
+                        '-o', out], check=True, capture_output=True)
+        return open(out).read()
+
+
+def audit(src, frag, skip, n_mfma, max_other):
+    text = device_asm(src)
+    problems, report = [], []
+    # split into functions
+    funcs = re.split(r'^(_Z\w+):', text, flags=re.M)
+    for name, body in zip(funcs[1::2], funcs[2::2]):
+        if frag not in name:
+            continue
+        if re.search(skip, name):
+            continue
+        # the steady-state loop body = the basic block(s) inside a loop (LLVM marks their label lines "Loop") holding
+        # exactly the iteration's MFMA count; the fewest other instructions wins when a peeled copy exists
+        parts = re.split(r'^(\.LBB\d+_\d+:.*)$', body.split('.Lfunc_end')[0], flags=re.M)
+        cands = [blk for lab, blk in zip(parts[1::2], parts[2::2])
+                 if 'Loop' in lab and len(re.findall(r'\bv_mfma_', blk)) == n_mfma]
+        if not cands:
+            problems.append(f'{name}: no loop block with {n_mfma} MFMAs')
+            continue
+        best = min(cands, key=lambda b: sum(1 for ln in b.splitlines() if ln.startswith('\t') and not ln.strip().startswith((';', '.'))))
+        ins = [ln.split()[0] for ln in best.splitlines() if ln.startswith('\t') and not ln.strip().startswith((';', '.'))]
+        mf = sum(1 for i in ins if i.startswith('v_mfma_'))
+        other = len(ins) - mf
+        bad = sorted({i for i in ins if i.startswith(FORBIDDEN)})
+        report.append(f'{name[:70]:70s} hot block: {mf} MFMA, {other} other instructions' + (f', FORBIDDEN {bad}' if bad else ''))
+        if other > max_other:
+            problems.append(f'{name}: {other} non-MFMA instructions in the hot block (limit {max_other})')
+        if bad:
+            problems.append(f'{name}: {bad} in the hot block')
+        acc_moves = sum(1 for i in ins if i.startswith('v_accvgpr_'))
+        if acc_moves > MAX_ACC_MOVES:
+            problems.append(f'{name}: {acc_moves} v_accvgpr moves in the hot block (limit {MAX_ACC_MOVES})')
+    if not report:
+        problems.append(f'{src}: no kernel matching {frag}')
+    return report, problems
+
+
+def main():
+    allp = []
+    for k in KERNELS:
+        rep, prob = audit(*k)
+        print('\n'.join(rep))
+        allp += prob
+    for p in allp:
+        print('VIOLATION:', p)
+    return 1 if allp else 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())
