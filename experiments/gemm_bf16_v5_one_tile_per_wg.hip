@@ -1,3 +1,6 @@
+// ARCHIVED (round 3): GEMM variant 5 — the 256x256x64 tile with one wave per SIMD, ONE tile per workgroup, 32x32x16 MFMA.
+// It was the default for the gated-residual epilogue in round 2; variant 7 (persistent loop on 16x16x32 MFMAs) replaced it
+// for every epilogue and variant 6 (its persistent form) stays in the library as the A/B partner.  Not built.
 // bf16 GEMM, variant 5: the 256 x 256 x 64 tile with FOUR waves (2x2, 128 tokens x 128 features each),
 // ONE wave per SIMD, accumulators in AGPRs.  Same reasoning as attn_hd128_w64.hip: a wave alone on
 // its SIMD hides its fragment reads (8 ds_read_b128 per 16 MFMAs) behind its own MFMAs, and an

@@ -134,8 +134,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(
     mg_gemm_epilogue<EPI, 2, 2>(acc, m0 + wm * 64, n0 + wn * 64, l31, g, M, N, bias, gate, out, ldo);
 }
 
-int mg_gemm_v5_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_t ldw, const float* bias, int64_t M,
-                      int N, int K, int epilogue, void* out, int64_t ldo, const float* gate, hipStream_t st);
 int mg_gemm_v6_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_t ldw, const float* bias, int64_t M,
                       int N, int K, int epilogue, void* out, int64_t ldo, const float* gate, hipStream_t st);
 int mg_gemm_v7_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_t ldw, const float* bias, int64_t M,
@@ -143,8 +141,10 @@ int mg_gemm_v7_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_
 int mg_gemm_v2_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_t ldw, const float* bias, int64_t M,
                       int N, int K, int epilogue, void* out, int64_t ldo, const float* gate, hipStream_t st);
 
-// tile schedule: 1 = 128x128 tile, 2 LDS stages (this file); 2 = 256x128, 3 stages (gemm_bf16_v2.hip); 5 = 256x256, 4 waves =
-// one per SIMD (gemm_bf16_v5.hip).  (3, the 8-wave 256x256 tile, was an A/B partner only: experiments/gemm_bf16_v3_8waves.hip.)
+// tile schedule: 7 = 256x256, 4 waves = one per SIMD, persistent, 16x16x32 MFMA (gemm_bf16_v7.hip; the default for M > 256 and
+// N > 128); 6 = the same loop on 32x32x16 MFMAs (gemm_bf16_v6.hip, A/B partner); 2 = 256x128, 3 stages (gemm_bf16_v2.hip; narrow
+// shapes); 1 = 128x128 tile, 2 LDS stages (this file; M <= 128).  Archived under experiments/: 3 (8-wave 256x256), 4 (16 waves),
+// 5 (one 256x256 tile per workgroup).
 // Process-global and NOT thread-safe on purpose: a measurement / test switch (tools/, tests/conftest.py resets it after
 // every test), never touched by the product path — mg_gemm_bf16 itself picks by shape.
 unsigned long long* g_gemm5_prof = nullptr;   // debug hook of the 256x256 kernels (variants 5 and 7): 4 waves x {wait+barrier, first half, second half, k-tiles}
@@ -169,9 +169,7 @@ extern "C" int mg_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* Wt, 
         return mg_gemm_v7_launch(A, lda, Wt, ldw, bias, M, N, K, epilogue, out, ldo, gate, (hipStream_t)stream);
     if (variant == 6 && M > 256 && N > 128)
         return mg_gemm_v6_launch(A, lda, Wt, ldw, bias, M, N, K, epilogue, out, ldo, gate, (hipStream_t)stream);
-    if (variant == 5 && M > 256 && N > 128)
-        return mg_gemm_v5_launch(A, lda, Wt, ldw, bias, M, N, K, epilogue, out, ldo, gate, (hipStream_t)stream);
-    if (variant >= 2 && M > 128)  // tiny M: the 128-row tile wastes less (variant 5 falls through to here for narrow shapes)
+    if (variant >= 2 && M > 128)  // tiny M: the 128-row tile wastes less (the 256x256 variants fall through to here for narrow shapes)
         return mg_gemm_v2_launch(A, lda, Wt, ldw, bias, M, N, K, epilogue, out, ldo, gate, (hipStream_t)stream);
     const int64_t tiles_m64 = (M + BM - 1) / BM;
     const int tiles_n = (N + BN - 1) / BN;

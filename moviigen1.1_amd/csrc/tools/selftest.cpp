@@ -600,7 +600,7 @@ int main(int argc, char** argv) {
         return n_fail ? 1 : 0;
     }
     if (argc > 1 && !strcmp(argv[1], "gemmshapes")) {   // the five GEMMs of a DiT block at 720p, with their epilogues
-        mg_gemm_set_variant(argc > 2 ? atoi(argv[2]) : 5);
+        mg_gemm_set_variant(argc > 2 ? atoi(argv[2]) : 7);
         const int64_t Mg = argc > 3 ? atoll(argv[3]) : 75600;   // 131040 = the 1920x832x81f token count
         test_gemm(Mg, 15360, 5120, 0, 128, true);     // q|k|v
         test_gemm(Mg, 5120, 5120, 2, 128, true);      // self-attention o (+ gate, residual)
@@ -613,9 +613,9 @@ int main(int argc, char** argv) {
         unsigned long long* buf;
         CK(hipMalloc(&buf, 32 * 8));
         CK(hipMemset(buf, 0, 32 * 8));
-        const int gv = argc > 2 ? atoi(argv[2]) : 2;
+        const int gv = argc > 2 ? atoi(argv[2]) : 7;
         mg_gemm_set_variant(gv);
-        if (gv == 5 || gv == 7 || gv >= 70) mg_gemm5_debug_profile(buf); else mg_gemm_debug_profile(buf);
+        if (gv == 7) mg_gemm5_debug_profile(buf); else mg_gemm_debug_profile(buf);
         test_gemm(argc > 3 ? atoll(argv[3]) : 75600, argc > 4 ? atoi(argv[4]) : 5120, argc > 5 ? atoi(argv[5]) : 5120, 0, 64, true);
         unsigned long long h[32];
         CK(hipMemcpy(h, buf, sizeof h, hipMemcpyDeviceToHost));
@@ -633,7 +633,7 @@ int main(int argc, char** argv) {
         return n_fail ? 1 : 0;
     }
     if (argc > 1 && !strcmp(argv[1], "gemm")) {
-        for (int variant : {1, 2, 5, 6, 7}) {
+        for (int variant : {1, 2, 6, 7}) {
             printf("== gemm variant %d ==\n", variant);
             mg_gemm_set_variant(variant);
             for (int epi = 0; epi < 4; ++epi) test_gemm(300, 256, 128, epi, 0, false);
