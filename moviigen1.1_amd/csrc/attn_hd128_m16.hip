@@ -161,29 +161,44 @@ MG_DEV void m16_step(M16State& s, const bf16x8_t (&qf)[4][4], bf16x8_t (&kf)[4],
     constexpr int SB = 1 - KB;          // unit being exponentiated
     float psa[4] = {0.f, 0.f, 0.f, 0.f}, psb[4] = {0.f, 0.f, 0.f, 0.f};
     u32x4_t w[4];
-    float pa = 0.f, pb = 0.f;
+    float pa[2] = {0.f, 0.f}, pb[2] = {0.f, 0.f};
     // softmax of pair pp = 2i + half (16 pairs per unit): query block n = pp >> 2, packed word pp & 3 = (key block,
-    // register pair).  In two parts so that the exps sit in front of a builtin MFMA and the adds / cvt in front of an asm one.
-    auto pair_a = [&](int i, int half) __attribute__((always_inline)) {   // exp, exp
+    // register pair); the pieces below are placed one by one into the eight MFMA gaps of a group
+    auto exp_a = [&](int i, int half) __attribute__((always_inline)) {
         if (SM) {
             const int pp = 2 * i + half, n = pp >> 2, wd = pp & 3;
-            if (SCALED) {
-                pa = __builtin_amdgcn_exp2f(s.st[SB][wd >> 1][n][(wd & 1) * 2] * c);
-                pb = __builtin_amdgcn_exp2f(s.st[SB][wd >> 1][n][(wd & 1) * 2 + 1] * c);
-            } else {
-                pa = __builtin_amdgcn_exp2f(s.st[SB][wd >> 1][n][(wd & 1) * 2]);
-                pb = __builtin_amdgcn_exp2f(s.st[SB][wd >> 1][n][(wd & 1) * 2 + 1]);
-            }
-            asm volatile("" : "+v"(pa), "+v"(pb));     // opaque use: pins the work HERE (LLVM sinks it otherwise)
+            const float x = s.st[SB][wd >> 1][n][(wd & 1) * 2];
+            pa[half] = __builtin_amdgcn_exp2f(SCALED ? x * c : x);
+            asm volatile("" : "+v"(pa[half]));     // opaque use: pins the work HERE (LLVM sinks it otherwise)
         }
     };
-    auto pair_b = [&](int i, int half) __attribute__((always_inline)) {   // add, add, cvt_pk
+    auto exp_b = [&](int i, int half) __attribute__((always_inline)) {
         if (SM) {
             const int pp = 2 * i + half, n = pp >> 2, wd = pp & 3;
-            psa[n] += pa;
-            psb[n] += pb;
-            unsigned pk = pack_bf2(pa, pb);
-            asm volatile("" : "+v"(pk), "+v"(psa[n]), "+v"(psb[n]));
+            const float x = s.st[SB][wd >> 1][n][(wd & 1) * 2 + 1];
+            pb[half] = __builtin_amdgcn_exp2f(SCALED ? x * c : x);
+            asm volatile("" : "+v"(pb[half]));
+        }
+    };
+    auto add_a = [&](int i, int half) __attribute__((always_inline)) {
+        if (SM) {
+            const int n = (2 * i + half) >> 2;
+            psa[n] += pa[half];
+            asm volatile("" : "+v"(psa[n]));
+        }
+    };
+    auto add_b = [&](int i, int half) __attribute__((always_inline)) {
+        if (SM) {
+            const int n = (2 * i + half) >> 2;
+            psb[n] += pb[half];
+            asm volatile("" : "+v"(psb[n]));
+        }
+    };
+    auto cvt = [&](int i, int half) __attribute__((always_inline)) {
+        if (SM) {
+            const int pp = 2 * i + half, n = pp >> 2, wd = pp & 3;
+            unsigned pk = pack_bf2(pa[half], pb[half]);
+            asm volatile("" : "+v"(pk));
             w[n][wd] = pk;
         }
     };
@@ -196,25 +211,11 @@ MG_DEV void m16_step(M16State& s, const bf16x8_t (&qf)[4][4], bf16x8_t (&kf)[4],
     auto P = [&](int i, int n) __attribute__((always_inline)) {
         if (PV) s.ot[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[i & 3], s.pf[KB][n], s.ot[i][n], 0, 0, 0);
     };
-#define M16_SB() __builtin_amdgcn_sched_barrier(0)
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    // ring slot (i+2)&3 was consumed two groups ago: it takes the read for group i+2.  (A ds_read whose result nobody
+    // uses would leave its destination free for reuse while the data is still on its way: steps without S^T MFMAs keep
+    // the previous occupant alive up to the read.)
+    auto rdK = [&](int i) __attribute__((always_inline)) {
         const int r2 = (i + 2) & 3;
-        m16_wait<2>();                         // K(i) and V(i) landed; younger: K(i+1), V(i+1)
-        M16_SB();
-        S(i, 0);
-        M16_SB();
-        pair_a(i, 0);
-        M16_SB();
-        P(i, 0);
-        M16_SB();
-        pair_b(i, 0);
-        M16_SB();
-        S(i, 1);
-        M16_SB();
-        // ring slot (i+2)&3 was consumed two groups ago: it takes the read for group i+2.  (A ds_read whose result
-        // nobody uses would leave its destination free for reuse while the data is still on its way: steps without
-        // S^T MFMAs keep the previous occupant alive up to here.)
         if (SMODE == 0) asm volatile("" ::"v"(kf[r2]));
         if (i < 6) {
             switch (i) {   // compile-time after unrolling
@@ -227,9 +228,9 @@ MG_DEV void m16_step(M16State& s, const bf16x8_t (&qf)[4][4], bf16x8_t (&kf)[4],
             }
         } else if (i == 6) m16_rd<m16_koff(0)>(kf[r2], nk);
         else m16_rd<m16_koff(1)>(kf[r2], nk);
-        M16_SB();
-        P(i, 1);
-        M16_SB();
+    };
+    auto rdV = [&](int i) __attribute__((always_inline)) {
+        const int r2 = (i + 2) & 3;
         if (i < 6) {
             switch (i) {
                 case 0: m16_rd<m16_voff(2)>(vf[r2], lds_v); break;
@@ -241,14 +242,40 @@ MG_DEV void m16_step(M16State& s, const bf16x8_t (&qf)[4][4], bf16x8_t (&kf)[4],
             }
         } else if (i == 6) m16_rd<m16_voff(0)>(vf[r2], nv);
         else m16_rd<m16_voff(1)>(vf[r2], nv);
+    };
+#define M16_SB() __builtin_amdgcn_sched_barrier(0)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        m16_wait<2>();                         // K(i) and V(i) landed; younger: K(i+1), V(i+1)
+        M16_SB();
+        // Eight MFMAs S0 P0 S1 P1 S2 P2 S3 P3 (asm / builtin alternate) and the gaps behind them:
+        //     [exp exp] [add add cvt] [rdK] [rdV] [exp exp] [add add cvt] [dma] [-]
+        // The "balanced" placement [exp rdK][exp add][add cvt rdV][exp][exp add][add cvt][dma][-] (never more than
+        // three fillers behind an MFMA) was measured: 2765 instead of 2652 cycles per tile, 1472 instead of 1505 TFLOP/s
+        // (profiles/r03g_attn_filler_schedule.log) — the exps want to sit together in front of a builtin MFMA.
+        S(i, 0);
+        M16_SB();
+        exp_a(i, 0); exp_b(i, 0);
+        M16_SB();
+        P(i, 0);
+        M16_SB();
+        add_a(i, 0); add_b(i, 0); cvt(i, 0);
+        M16_SB();
+        S(i, 1);
+        M16_SB();
+        rdK(i);
+        M16_SB();
+        P(i, 1);
+        M16_SB();
+        rdV(i);
         M16_SB();
         S(i, 2);
         M16_SB();
-        pair_a(i, 1);
+        exp_a(i, 1); exp_b(i, 1);
         M16_SB();
         P(i, 2);
         M16_SB();
-        pair_b(i, 1);
+        add_a(i, 1); add_b(i, 1); cvt(i, 1);
         M16_SB();
         S(i, 3);
         M16_SB();

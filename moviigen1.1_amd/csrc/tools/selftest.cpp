@@ -356,6 +356,9 @@ static void attn_ab(int64_t L, int heads, int data, const std::vector<int>& vari
     Dev<uint16_t> dq(q), dk(k), dv(v), dkp((size_t)npk), dvp((size_t)npk), dout((size_t)L * ld);
     Dev<unsigned> cnt(1);
     const float scale = 1.f / sqrtf(128.f);
+    std::vector<uint16_t> qs(q.size());          // variants >= 10: the pre-scaled entry on bf16(q * scale*log2e)
+    for (size_t i = 0; i < q.size(); ++i) qs[i] = f2bf(bf2f(q[i]) * scale * 1.4426950408889634f);
+    Dev<uint16_t> dqs(qs);
     int rc = mg_pack_kv_bf16(dk.p, ld, dv.p, ld, L, heads, 128, dkp.p, dvp.p, 0);
     if (rc) { printf("pack_kv failed %d\n", rc); ++n_fail; return; }
     mg_attn_w64_flag_counter(cnt.p);
@@ -389,14 +392,21 @@ static void attn_ab(int64_t L, int heads, int data, const std::vector<int>& vari
     }
     for (int r = 0; r < rounds; ++r)
         for (int var : variants) {
-            mg_attn_set_variant(var);
+            // variant: 0 = m16 general entry, 3 = w64; 10 + k = m16 through the pre-scaled entry with debug flags 2*k
+            // (k = 1: the alternative filler schedule)
+            mg_attn_set_variant(var >= 10 ? 0 : var);
+            mg_attn_w64_debug(var >= 10 ? 2 * (var - 10) : 0);
             rc = mg_pack_kv_bf16(dk.p, ld, dv.p, ld, L, heads, 128, dkp.p, dvp.p, 0);   // the K row order follows the kernel
             cnt.zero();
             CK(hipMemset(dout.p, 0xff, dout.n * 2));
-            rc |= mg_attn_fwd_bf16_hd128(dq.p, ld, dkp.p, dvp.p, dout.p, ld, L, L, heads, scale, 0);
+            auto run = [&]() {
+                return var >= 10 ? mg_attn_fwd_bf16_hd128_prescaled(dqs.p, ld, dkp.p, dvp.p, dout.p, ld, nullptr, L, L, heads, 0)
+                                 : mg_attn_fwd_bf16_hd128(dq.p, ld, dkp.p, dvp.p, dout.p, ld, L, L, heads, scale, 0);
+            };
+            rc |= run();
             CK(hipDeviceSynchronize());
             const unsigned flagged = cnt.host()[0];
-            float ms = time_ms([&] { mg_attn_fwd_bf16_hd128(dq.p, ld, dkp.p, dvp.p, dout.p, ld, L, L, heads, scale, 0); }, 3);
+            float ms = time_ms([&] { run(); }, 3);
             auto got = dout.host();
             double err = rc ? 1e9 : 0;
             for (int it = 0; it < nsamp; ++it)
@@ -409,6 +419,7 @@ static void attn_ab(int64_t L, int heads, int data, const std::vector<int>& vari
             fflush(stdout);
         }
     mg_attn_w64_flag_counter(nullptr);
+    mg_attn_w64_debug(0);
     mg_attn_set_variant(0);
 }
 
@@ -583,6 +594,7 @@ int main(int argc, char** argv) {
         CK(hipMemset(buf, 0, 16 * 8));
         mg_attn_set_variant(argc > 4 ? atoi(argv[4]) : 0);
         mg_attn_w64_profile(buf);                // (both kernels share the hook)
+        if (argc > 6) mg_attn_w64_debug(atoi(argv[6]));
         test_attn(75600, argc > 2 ? atoll(argv[2]) : 75584, argc > 3 ? atoi(argv[3]) : 8, 8, true, argc > 5 ? atoi(argv[5]) : 1);
         unsigned long long h[16];
         CK(hipMemcpy(h, buf, sizeof h, hipMemcpyDeviceToHost));
