@@ -24,8 +24,10 @@ the layer becomes a software pipeline over them —
     On the fully connected xGMI mesh an all-to-all sends each peer its 1/P slice over its own direct
     link, all 7 links concurrently.  Tokens are sharded contiguously: rank r owns [r*L/P, (r+1)*L/P).
 
-`gloo` with CUDA tensors (the multi-process tests on a 1-GPU box) is staged through host memory —
-test plumbing only; production is RCCL, device to device.  `seq_to_head` / `head_to_seq` keep the
+Transports of the exchange: torch.distributed backend "nccl" (= RCCL; default), the library's own RCCL communicator
+(MOVIIGEN_SP_TRANSPORT=rccl_direct: C-ABI mg_sp_all_to_all) or one-sided peer copies on the copy engines
+(MOVIIGEN_SP_TRANSPORT=peer_copy: peer_copy.py).  `gloo` with CUDA tensors (the multi-process tests on a 1-GPU box) is
+staged through host memory — test plumbing only; production is device to device.  `seq_to_head` / `head_to_seq` keep the
 one-tensor call shape of the reference libraries (used by the training-side SP forward and tests).
 """
 import os
@@ -34,7 +36,7 @@ import torch
 import torch.distributed as dist
 
 from ..backend import ops
-from . import rccl_direct
+from . import peer_copy, rccl_direct
 
 
 def _a2a(recv, send, group):
@@ -109,6 +111,11 @@ class HeadExchange:
             self.recv.append(e(P * Lloc, 3 * w))
             self.ag.append(e(P * Lloc, w))
             self.orecv.append(e(P, Lloc, w))
+        # MOVIIGEN_SP_TRANSPORT=peer_copy: the receive buffers are mapped into the peers once; an exchange is then P
+        # one-sided device copies on the comm stream (copy engines, no CUs) between two 4-byte rendezvous
+        self.peer = None
+        if peer_copy.enabled() and self.recv[0].is_cuda and group is not None:
+            self.peer = peer_copy.PeerWindows(group, self.recv + self.orecv)
         self.comm = torch.cuda.Stream(device=device)
         ev = lambda: [torch.cuda.Event() for _ in self.groups]  # noqa: E731
         self.ev_pack, self.ev_recv, self.ev_attn, self.ev_o = ev(), ev(), ev(), ev()
@@ -125,7 +132,10 @@ class HeadExchange:
             for g in range(len(self.groups)):
                 self.comm.wait_event(self.ev_pack[g])
                 self._mark('comm', self.comm)
-                _a2a(self.recv[g].view(P, self.Lloc, -1), self.send[g], self.group)
+                if self.peer is not None:
+                    self.peer.all_to_all(g, self.send[g])
+                else:
+                    _a2a(self.recv[g].view(P, self.Lloc, -1), self.send[g], self.group)
                 self._mark('comm', self.comm)
                 self.ev_recv[g].record(self.comm)
         for g, (h0, n) in enumerate(self.groups):
@@ -139,7 +149,10 @@ class HeadExchange:
             with torch.cuda.stream(self.comm):
                 self.comm.wait_event(self.ev_attn[g])
                 self._mark('comm', self.comm)
-                _a2a(self.orecv[g], self.ag[g].view(P, self.Lloc, w), self.group)
+                if self.peer is not None:
+                    self.peer.all_to_all(len(self.groups) + g, self.ag[g].view(P, self.Lloc, w))
+                else:
+                    _a2a(self.orecv[g], self.ag[g].view(P, self.Lloc, w), self.group)
                 self._mark('comm', self.comm)
                 self.ev_o[g].record(self.comm)
         for g, (h0, n) in enumerate(self.groups):

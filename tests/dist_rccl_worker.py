@@ -70,6 +70,12 @@ m._ws = {}
 got = m([lat], t=t, context=[ctx], seq_len=32)[0]                          # sp_force is still on: exchange via mg_sp_all_to_all
 assert torch.equal(got, ref), (got - ref).abs().max().item()
 print('RCCL_DIRECT_OK', flush=True)
+os.environ['MOVIIGEN_SP_TRANSPORT'] = 'peer_copy'                          # one-sided copies between two RCCL flag all-reduces
+m._ws = {}
+got = m([lat], t=t, context=[ctx], seq_len=32)[0]
+xch = m._ws[next(iter(m._ws))]['xchg']
+assert xch.peer is not None and torch.equal(got, ref), (got - ref).abs().max().item()
+print('PEER_COPY_OK', flush=True)
 m.sp_force = False
 m = fsdp.shard_model(m, device_id=0)
 got = m([lat], t=t, context=[ctx], seq_len=32)[0]

@@ -867,8 +867,8 @@ def _run_hybrid(world, backend, layout, port, transport='torch'):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MOVIIGEN_TEST_BACKEND=backend, MOVIIGEN_TEST_LAYOUT=layout, HSA_ENABLE_IPC_MODE_LEGACY='0')
-    if transport == 'rccl_direct':      # the C-ABI collectives on the library's own communicator (mg_sp_all_to_all, ...)
-        env['MOVIIGEN_SP_TRANSPORT'] = 'rccl_direct'
+    if transport != 'torch':            # rccl_direct: the C-ABI collectives on the library's own communicator
+        env['MOVIIGEN_SP_TRANSPORT'] = transport        # (mg_sp_all_to_all, ...); peer_copy: one-sided copies into IPC-mapped buffers
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={world}',
                         '--master-addr', '127.0.0.1', '--master-port', str(port),
                         os.path.join(root, 'tests', 'dist_hybrid_worker.py')], capture_output=True, text=True, timeout=900,
@@ -886,7 +886,15 @@ def test_config3_composition_one_gpu(world, layout):
     _run_hybrid(world, 'gloo', layout, 29600 + world + (0 if layout == 'cfg_sp_fsdp' else 10))
 
 
-@pytest.mark.parametrize('transport', ['torch', 'rccl_direct'])
+def test_peer_copy_transport_one_gpu():
+    """MOVIIGEN_SP_TRANSPORT=peer_copy: the exchange as one-sided device copies into the peers' receive buffers (IPC
+    handles exchanged once, hipMemcpyAsync D2D on the comm stream between two rendezvous).  Here: 2 ranks sharing
+    cuda:0 (the handles cross a process boundary; the rendezvous is gloo's host barrier), Ulysses over both ranks +
+    block shards, bit-identical to the unsharded forward at every pipeline depth."""
+    _run_hybrid(2, 'gloo', 'sp_fsdp', 29671, 'peer_copy')
+
+
+@pytest.mark.parametrize('transport', ['torch', 'rccl_direct', 'peer_copy'])
 @pytest.mark.parametrize('layout', ['cfg_sp_fsdp', 'sp_fsdp'])
 def test_rccl_multi_gpu(layout, transport):
     """the production transport with MORE than one rank: backend nccl (= RCCL over xGMI), one rank per visible GPU
@@ -895,7 +903,7 @@ def test_rccl_multi_gpu(layout, transport):
     if n < 2:
         pytest.skip('needs >= 2 GPUs (RCCL refuses two ranks on one device)')
     world = 8 if n >= 8 else 4 if n >= 4 else 2
-    _run_hybrid(world, 'nccl', layout, 29630 + world + (20 if transport == 'rccl_direct' else 0), transport)
+    _run_hybrid(world, 'nccl', layout, 29630 + world + {'torch': 0, 'rccl_direct': 20, 'peer_copy': 40}[transport], transport)
 
 
 def test_train_side_sp_forward_one_gpu():
@@ -1184,7 +1192,7 @@ def test_rccl_backend_single_rank():
     r = subprocess.run([sys.executable, os.path.join(root, 'tests', 'dist_rccl_worker.py')], capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    for tag in ('RCCL_COLLECTIVES_OK', 'RCCL_SP_BRANCH_OK', 'RCCL_DIRECT_OK', 'RCCL_FSDP_OK'):
+    for tag in ('RCCL_COLLECTIVES_OK', 'RCCL_SP_BRANCH_OK', 'RCCL_DIRECT_OK', 'PEER_COPY_OK', 'RCCL_FSDP_OK'):
         assert tag in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 

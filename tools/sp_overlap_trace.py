@@ -6,7 +6,9 @@
 The worker runs the PRODUCTION transport — backend "nccl" (= RCCL) — with the sequence-parallel branch forced on a
 1-rank group (a 1-GPU box cannot hold two RCCL ranks; with one rank the all-to-all is RCCL's own device copy kernel on
 RCCL's stream, so the stream / event structure is exactly the multi-GPU one): a DiT of width 1024 (8 heads x 128),
-16 384 tokens, 2 layers, exchange pipelined over 4 head groups.  The analysis intersects the time intervals of the
+16 384 tokens, 2 layers, exchange pipelined over MOVIIGEN_SP_GROUPS head groups (default 4; 8 = one head per group =
+16 384 x 384 x 2 B = 12.6 MB per exchange, the per-peer message of BASELINE configs[2] at P = 8: 16 380 rows x 1 head x
+(q|k|v) x 128 x 2 B).  MOVIIGEN_SP_TRANSPORT selects the transport as in production.  The analysis intersects the time intervals of the
 RCCL kernels with those of the attention kernels of the same process: a non-zero overlap = the exchange of group g+1 /
 the return of group g-1 really run under the attention of group g."""
 import csv
@@ -26,7 +28,7 @@ def run():
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29688')
-    os.environ['MOVIIGEN_SP_GROUPS'] = '4'
+    os.environ.setdefault('MOVIIGEN_SP_GROUPS', '4')
     torch.cuda.set_device(0)
     dev = torch.device('cuda:0')
     dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
@@ -54,7 +56,7 @@ def analyse(d, out=None):
             rows.append((r['Kernel_Name'], int(r['Start_Timestamp']), int(r['End_Timestamp']),
                          r.get('Stream_Id', r.get('Queue_Id', '?'))))
     attn = [(s, e) for n, s, e, _ in rows if 'attn_hd128' in n]
-    comm = [(s, e, n) for n, s, e, _ in rows if 'nccl' in n.lower() or 'rccl' in n.lower()]
+    comm = [(s, e, n) for n, s, e, _ in rows if 'nccl' in n.lower() or 'rccl' in n.lower() or 'copyBuffer' in n]     # RCCL kernels; blit copies of the peer_copy transport (same-device loop-back: no SDMA)
     pack = [(s, e) for n, s, e, _ in rows if 'sp_copy_blocks' in n]
     attn.sort()
 
@@ -71,7 +73,7 @@ def analyse(d, out=None):
     c_tot = sum(e - s for s, e, _ in comm)
     c_ov = overlap([(s, e) for s, e, _ in comm])
     label = os.environ.get('SP_TRACE_LABEL', 'default')
-    lines = [f'# tools/sp_overlap_trace.py [{label}]: rocprofv3 --kernel-trace of the pipelined Ulysses exchange, backend nccl (RCCL), 1 rank, 4 head groups',
+    lines = [f'# tools/sp_overlap_trace.py [{label}]: rocprofv3 --kernel-trace of the pipelined Ulysses exchange, backend nccl (RCCL), 1 rank, ' + os.environ.get('MOVIIGEN_SP_GROUPS', '4') + ' head groups, transport ' + (os.environ.get('MOVIIGEN_SP_TRANSPORT') or 'torch') + ',',
              f'attention kernels          : n={len(attn)} total_us={sum(b - a for a, b in attn) / 1e3:.1f}',
              f'RCCL kernels (all-to-all)  : n={len(comm)} total_us={c_tot / 1e3:.1f}  names={sorted({n.split("(")[0][:50] for _, _, n in comm})}',
              f'  of which UNDER attention : {c_ov / 1e3:.1f} us = {100.0 * c_ov / max(c_tot, 1):.1f} % of the RCCL kernel time',
