@@ -1,3 +1,5 @@
+// ARCHIVED (round 3): GEMM variant 6 — the persistent 256x256x64 loop with one wave per SIMD on 32x32x16 MFMAs (the
+// round-2 default).  Variant 7 is the same loop on 16x16x32 MFMAs (+2-4 %), variant 8 its 8-wave ping-pong form.  Not built.
 // bf16 GEMM, variant 6: variant 5's tile and k-loop (256 x 256 x 64, four waves = one per SIMD, AGPR accumulators,
 // LDS-DMA pieces and hand-issued fragment reads between the MFMAs) inside a PERSISTENT tile loop: one workgroup per
 // CU walks the tile list, and the refill slot of a tile's LAST k-tile — which variant 5 spends on a redundant re-load —

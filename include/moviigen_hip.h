@@ -104,11 +104,12 @@ int mg_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw,
                  int64_t ldo, const float* gate, void* stream);
 
 /* Tile schedule of mg_gemm_bf16 (same results bit for bit) — a process-global MEASUREMENT / TEST switch, not part of
- * the drop-in contract and not thread-safe; the default (0) selects by shape (7 for M > 256 and N > 128, else 2 / 1):
- * 7 = 256x256x64 tile, 4 waves = ONE per SIMD (128x128 each, accumulators in AGPRs), v_mfma_f32_16x16x32_bf16, persistent
- *     loop (one workgroup per CU; the first k-tile of the next tile is fetched during the last k-tile of the current
- *     one), LDS-DMA pieces and fragment reads spread between the MFMAs;
- * 6 = the same loop on v_mfma_f32_32x32x16_bf16 (the round-2 kernel, A/B partner);
+ * the drop-in contract and not thread-safe; the default (0) selects by shape (8 for M > 256 and N > 128, else 2 / 1):
+ * 8 = 256x256x64 tile, v_mfma_f32_16x16x32_bf16, persistent loop (one workgroup per CU; the first k-tile of the next
+ *     tile is fetched during the last k-tile of the current one), EIGHT waves in two ping-pong groups: in every interval
+ *     between two barriers one group issues 16 MFMAs per wave while its SIMD partners read fragments and issue LDS-DMA;
+ * 7 = the same tile and loop with 4 waves = ONE per SIMD (128x128 each), LDS-DMA pieces and fragment reads spread
+ *     between the wave's own MFMAs (A/B partner);
  * 2 = 256x128x64 tile, 8 waves, 3-stage LDS ring with counted vmcnt (M > 128, else 1);
  * 1 = 128x128x64 tile, 4 waves, 2 stages. */
 void mg_gemm_set_variant(int variant);
@@ -356,7 +357,7 @@ void mg_attn_w64_profile(unsigned long long* dev_buf);     /* both attention ker
 void mg_attn_w64_debug(int flags);                         /* bit 0: keep the pipelined result of flagged blocks (no exact pass) */
 void mg_attn_w64_flag_counter(unsigned* dev_counter);      /* both kernels: *dev_counter += query blocks redone by the exact pass */
 void mg_gemm_debug_profile(unsigned long long* dev_buf);   /* GEMM variants 1/2: 8 waves x {wait+barrier, stage issue, MFMA, k-tiles} */
-void mg_gemm5_debug_profile(unsigned long long* dev_buf);   /* GEMM variant 7: 4 waves x {wait+barrier, k-step 0, k-step 1, k-tiles} */
+void mg_gemm5_debug_profile(unsigned long long* dev_buf);   /* GEMM variant 7: 4 waves x {wait+barrier, k-step 0, k-step 1, k-tiles}; 8: 8 waves x {load, wait, MFMA, wait, phases} (64 words) */
 
 #ifdef __cplusplus
 }

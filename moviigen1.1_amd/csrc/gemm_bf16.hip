@@ -134,17 +134,17 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(
     mg_gemm_epilogue<EPI, 2, 2>(acc, m0 + wm * 64, n0 + wn * 64, l31, g, M, N, bias, gate, out, ldo);
 }
 
-int mg_gemm_v6_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_t ldw, const float* bias, int64_t M,
-                      int N, int K, int epilogue, void* out, int64_t ldo, const float* gate, hipStream_t st);
 int mg_gemm_v7_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_t ldw, const float* bias, int64_t M,
+                      int N, int K, int epilogue, void* out, int64_t ldo, const float* gate, hipStream_t st);
+int mg_gemm_v8_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_t ldw, const float* bias, int64_t M,
                       int N, int K, int epilogue, void* out, int64_t ldo, const float* gate, hipStream_t st);
 int mg_gemm_v2_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_t ldw, const float* bias, int64_t M,
                       int N, int K, int epilogue, void* out, int64_t ldo, const float* gate, hipStream_t st);
 
-// tile schedule: 7 = 256x256, 4 waves = one per SIMD, persistent, 16x16x32 MFMA (gemm_bf16_v7.hip; the default for M > 256 and
-// N > 128); 6 = the same loop on 32x32x16 MFMAs (gemm_bf16_v6.hip, A/B partner); 2 = 256x128, 3 stages (gemm_bf16_v2.hip; narrow
-// shapes); 1 = 128x128 tile, 2 LDS stages (this file; M <= 128).  Archived under experiments/: 3 (8-wave 256x256), 4 (16 waves),
-// 5 (one 256x256 tile per workgroup).
+// tile schedule: 8 = 256x256, 8 waves in two ping-pong groups, persistent, 16x16x32 MFMA (gemm_bf16_v8.hip; the default for
+// M > 256 and N > 128); 7 = the same tile with 4 waves = one per SIMD (gemm_bf16_v7.hip, A/B partner); 2 = 256x128, 3 stages
+// (gemm_bf16_v2.hip; narrow shapes); 1 = 128x128 tile, 2 LDS stages (this file; M <= 128).  Archived under experiments/: 3 (8-wave
+// 256x256 on 32x32x16), 4 (16 waves), 5 (one 256x256 tile per workgroup), 6 (persistent, 32x32x16), 9 (8 with a ring refill).
 // Process-global and NOT thread-safe on purpose: a measurement / test switch (tools/, tests/conftest.py resets it after
 // every test), never touched by the product path — mg_gemm_bf16 itself picks by shape.
 unsigned long long* g_gemm5_prof = nullptr;   // debug hook of the 256x256 kernels (variants 5 and 7): 4 waves x {wait+barrier, first half, second half, k-tiles}
@@ -162,13 +162,14 @@ extern "C" int mg_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* Wt, 
     if (bias && ((uintptr_t)bias & 15)) return MG_ERR_SHAPE;
     if (gate && ((uintptr_t)gate & 15)) return MG_ERR_SHAPE;
     if (M == 0) return MG_OK;
-    // default: variant 7, the persistent 256x256 loop on 16x16x32 MFMAs (profiles/r03d_gemmshapes_*: +1.6 % q|k|v,
-    // +3.8 % self-attn o, +4 % cross q, +0 % ffn.0, +1.7 % ffn.2 over the better of 5 / 6 at M = 131 040)
-    const int variant = g_gemm_variant ? g_gemm_variant : 7;
+    // default: variant 8, the persistent 256x256 loop on 16x16x32 MFMAs with eight waves in two ping-pong groups
+    // (profiles/r03j_gemm_v7_v8_v9.log: +1.5 ... +4 % over variant 7 = the same loop with one wave per SIMD, which was
+    // +2 ... +4 % over the 32x32x16 kernels of round 2, profiles/r03d_gemmshapes_*)
+    const int variant = g_gemm_variant ? g_gemm_variant : 8;
+    if (variant >= 8 && M > 256 && N > 128)
+        return mg_gemm_v8_launch(A, lda, Wt, ldw, bias, M, N, K, epilogue, out, ldo, gate, (hipStream_t)stream);
     if (variant == 7 && M > 256 && N > 128)
         return mg_gemm_v7_launch(A, lda, Wt, ldw, bias, M, N, K, epilogue, out, ldo, gate, (hipStream_t)stream);
-    if (variant == 6 && M > 256 && N > 128)
-        return mg_gemm_v6_launch(A, lda, Wt, ldw, bias, M, N, K, epilogue, out, ldo, gate, (hipStream_t)stream);
     if (variant >= 2 && M > 128)  // tiny M: the 128-row tile wastes less (the 256x256 variants fall through to here for narrow shapes)
         return mg_gemm_v2_launch(A, lda, Wt, ldw, bias, M, N, K, epilogue, out, ldo, gate, (hipStream_t)stream);
     const int64_t tiles_m64 = (M + BM - 1) / BM;

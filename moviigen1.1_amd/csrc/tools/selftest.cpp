@@ -612,7 +612,7 @@ int main(int argc, char** argv) {
         return n_fail ? 1 : 0;
     }
     if (argc > 1 && !strcmp(argv[1], "gemmshapes")) {   // the five GEMMs of a DiT block at 720p, with their epilogues
-        mg_gemm_set_variant(argc > 2 ? atoi(argv[2]) : 7);
+        mg_gemm_set_variant(argc > 2 ? atoi(argv[2]) : 8);
         const int64_t Mg = argc > 3 ? atoll(argv[3]) : 75600;   // 131040 = the 1920x832x81f token count
         test_gemm(Mg, 15360, 5120, 0, 128, true);     // q|k|v
         test_gemm(Mg, 5120, 5120, 2, 128, true);      // self-attention o (+ gate, residual)
@@ -623,14 +623,21 @@ int main(int argc, char** argv) {
     }
     if (argc > 1 && !strcmp(argv[1], "gemmprof")) {  // s_memtime breakdown of the 256x128 GEMM k-loop
         unsigned long long* buf;
-        CK(hipMalloc(&buf, 32 * 8));
-        CK(hipMemset(buf, 0, 32 * 8));
+        CK(hipMalloc(&buf, 64 * 8));
+        CK(hipMemset(buf, 0, 64 * 8));
         const int gv = argc > 2 ? atoi(argv[2]) : 7;
         mg_gemm_set_variant(gv);
-        if (gv == 7) mg_gemm5_debug_profile(buf); else mg_gemm_debug_profile(buf);
+        if (gv >= 7) mg_gemm5_debug_profile(buf); else mg_gemm_debug_profile(buf);
         test_gemm(argc > 3 ? atoll(argv[3]) : 75600, argc > 4 ? atoi(argv[4]) : 5120, argc > 5 ? atoi(argv[5]) : 5120, 0, 64, true);
-        unsigned long long h[32];
+        unsigned long long h[64];
         CK(hipMemcpy(h, buf, sizeof h, hipMemcpyDeviceToHost));
+        if (gv >= 8) {      // ping-pong kernels: waves 0-3 = group X, 4-7 = group Y; per PHASE (4 phases = one k-tile of 64 MFMAs per wave)
+            for (int w = 0; w < 8; ++w) {
+                const double n = (double)h[w * 5 + 4];
+                printf("wave %d: phases %.0f  load part %.0f  barrier-1 wait %.0f  MFMA part %.0f  barrier-2 wait %.0f  (cycles per phase; x4 per k-tile)\n",
+                       w, n, h[w * 5] / n, h[w * 5 + 1] / n, h[w * 5 + 2] / n, h[w * 5 + 3] / n);
+            }
+        } else
         for (int w = 0; w < 8; ++w) {
             const double n = (double)h[w * 4 + 3];
             printf("wave %d: k-tiles %.0f  wait+barrier %.0f  stage issue %.0f  MFMA segment %.0f  (cycles per k-tile)\n", w, n,
@@ -645,7 +652,7 @@ int main(int argc, char** argv) {
         return n_fail ? 1 : 0;
     }
     if (argc > 1 && !strcmp(argv[1], "gemm")) {
-        for (int variant : {1, 2, 6, 7}) {
+        for (int variant : {1, 2, 7, 8}) {
             printf("== gemm variant %d ==\n", variant);
             mg_gemm_set_variant(variant);
             for (int epi = 0; epi < 4; ++epi) test_gemm(300, 256, 128, epi, 0, false);

@@ -21,6 +21,7 @@ HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 # source file, kernel name fragment, regex of instantiations to skip (the s_memtime profiling builds), MFMAs per
 # iteration, max other instructions per iteration
 KERNELS = [
+    ('gemm_bf16_v8.hip', 'gemm_bf16_v8_kernel', r'kernelILi\dELb1E', 64, 120),
     ('gemm_bf16_v7.hip', 'gemm_bf16_v7_kernel', r'kernelILi\dELb1E', 128, 180),
     ('attn_hd128_m16.hip', 'attn_hd128_m16_kernel', r'kernelILb1E', 128, 330),
 ]
