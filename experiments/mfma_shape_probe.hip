@@ -17,7 +17,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 #define SB() __builtin_amdgcn_sched_barrier(0)
 
-template <int SHAPE, int FILL, int WAVES>
+template <int SHAPE, int FILL, int WAVES, int RDS = 1>
 __global__ __launch_bounds__(WAVES * 64, 1) void mix(const u32x4_t* __restrict__ in, float* __restrict__ out, int iters,
                                                      unsigned long long* __restrict__ cyc) {
     __shared__ __attribute__((aligned(16))) char smem[96 * 1024];      // one workgroup per CU
@@ -90,6 +90,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void mix(const u32x4_t* __restrict__
                     asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(y[(j + f) & 3]), "v"(y[(j + f + 2) & 3]));
             }
             if (FILL >= 0) a[(j + 2) & 3] = *(const bf16x8_t*)(lp + ((j * 1024 + it * 8192) & 0xfc00));
+            if (RDS >= 2) b[(j + 2) & 3] = *(const bf16x8_t*)(lp + ((j * 1024 + it * 8192 + 32768) & 0xfc00));   // 32-query waves: twice the fragment reads per MFMA
             SB();
         }
     }
@@ -105,16 +106,16 @@ __global__ __launch_bounds__(WAVES * 64, 1) void mix(const u32x4_t* __restrict__
     if (tid == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
-template <int SHAPE, int FILL, int WAVES>
+template <int SHAPE, int FILL, int WAVES, int RDS = 1>
 static void run(const u32x4_t* in, float* out, unsigned long long* cyc, int rounds) {
     const int iters = 20000, grid = 1024;
     for (int r = 0; r < rounds; ++r) {
         hipEvent_t e0, e1;
         CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-        hipLaunchKernelGGL((mix<SHAPE, FILL, WAVES>), dim3(grid), dim3(WAVES * 64), 0, 0, in, out, 2000, cyc);
+        hipLaunchKernelGGL((mix<SHAPE, FILL, WAVES, RDS>), dim3(grid), dim3(WAVES * 64), 0, 0, in, out, 2000, cyc);
         CK(hipDeviceSynchronize());
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL((mix<SHAPE, FILL, WAVES>), dim3(grid), dim3(WAVES * 64), 0, 0, in, out, iters, cyc);
+        hipLaunchKernelGGL((mix<SHAPE, FILL, WAVES, RDS>), dim3(grid), dim3(WAVES * 64), 0, 0, in, out, iters, cyc);
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
         float ms;
@@ -125,8 +126,8 @@ static void run(const u32x4_t* in, float* out, unsigned long long* cyc, int roun
         for (auto v : h) cs += (double)v;
         cs /= grid;
         const double flops = (double)grid * WAVES * iters * 8 * 65536.0;
-        printf("%s  waves/CU %d  fill x%d (VALU per 32x32x16-equivalent: %.1f) + 0.5 ds_read: %8.1f TF/s  %6.1f cyc per 32768 FLOP  (clock ~%.2f GHz)\n",
-               SHAPE ? "16x16x32" : "32x32x16", WAVES, FILL, FILL * 2.5, flops / (ms * 1e-3) / 1e12, cs / (iters * 16.0),
+        printf("%s  waves/CU %d  fill x%d (VALU per 32x32x16-equivalent: %.1f) + %.1f ds_read: %8.1f TF/s  %6.1f cyc per 32768 FLOP  (clock ~%.2f GHz)\n",
+               SHAPE ? "16x16x32" : "32x32x16", WAVES, FILL, FILL * 2.5, 0.5 * RDS, flops / (ms * 1e-3) / 1e12, cs / (iters * 16.0),
                cs * (grid / 256.0) / (ms * 1e-3) / 1e9 / 1.0);
         fflush(stdout);
     }
@@ -152,6 +153,8 @@ int main() {
         run<1, 2, 4>(in, out, cyc, 1);
         run<0, 1, 8>(in, out, cyc, 1);
         run<1, 1, 8>(in, out, cyc, 1);
+        run<1, 1, 8, 2>(in, out, cyc, 1);
+        run<1, 1, 4, 2>(in, out, cyc, 1);
     }
     return 0;
 }
