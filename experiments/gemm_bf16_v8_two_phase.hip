@@ -1,0 +1,324 @@
+// ARCHIVED EXPERIMENT (round 3): gemm_bf16_v8.hip with the template switch PH2 = TWO phases per k-tile (one per 32-deep
+// k-step: 12 fragment reads | 32 MFMAs) instead of four — half the barriers per MFMA.  It was wired as
+// mg_gemm_set_variant(10) (launcher argument two_phase).  Correct on the whole selftest shape set, both forms:
+//   plain (all 8 pieces in the load part of k-step 0, awaited in the load part of k-step 1: two barrier intervals):
+//       1248 vs 1292 TFLOP/s on q|k|v at M = 131040, load part 398-636 cycles: the pieces' landing time is exposed;
+//   skewed (this file: group Y issues its pieces of k-tile t+2 BETWEEN the MFMAs of k-step 1, X awaits after its MFMAs:
+//       four intervals for both): 1180 vs 1290 — a global_load_lds stalls its wave 30-100 cycles and, in order, the
+//       MFMAs behind it: Y's MFMA part takes 1040 instead of 512 cycles (profiles/r03n_gemm_two_phase_skewed.log).
+// With two 64 KiB stages the refill window is four intervals and DMA issue is only free in load parts: there is no
+// placement that has both.  A 32-deep k-tile with four 32 KiB stages would (window of six intervals) — but the PMC pass
+// of variant 8 (profiles/r03n_pmc_gemm_v8.txt: matrix pipe busy 64.3 % vs 58.0 % for variant 7, i.e. -10 % cycles for
+// -3.7 % time) shows the GEMM at the power cap as well: cycles saved come back at ~40 %.  Not compiled.
+// bf16 GEMM, variant 8: the 256 x 256 x 64 tile of variant 7 with EIGHT waves in two ping-pong groups — the structure that
+// hides a wave's LDS-DMA issue and fragment reads behind its SIMD partner's MFMAs (cdna guide 5: the 8-phase idea, built
+// here on this library's LDS image and refill protocol).
+//
+// Why: variant 7 (one wave per SIMD) is issue-limited, not power-limited: 58 % matrix-pipe occupancy at 2.08 GHz; per
+// k-tile 1774 cycles for the 64 MFMAs of the k-step that carries the wave's 16 LDS-DMA pieces vs 1036 without
+// — a wave that issues a piece or waits for fragments blocks its own MFMAs and nothing else runs on that SIMD.
+//
+// Structure: waves 0-3 (group X: tokens 0-127 of the tile) and 4-7 (group Y: tokens 128-255); wave w and w + 4 share a
+// SIMD.  A wave owns 128 tokens x 64 features (4 x 8 accumulators of 4 registers = 128 AGPRs; <= 256 registers per wave).
+// A k-tile is FOUR phases per wave; a phase = { load part: fragment reads (8 / 4 / 8 / 4 ds_read_b128) + 4 LDS-DMA pieces
+// of the next k-tile in phases 0 and 1; lgkmcnt(0) ; s_barrier ; 16 MFMAs (4 feature x 4 token blocks, one 32-deep k-step)
+// ; s_barrier }.  Group Y runs ONE barrier behind group X (an extra barrier at its start, one at X's end), so in every
+// interval between two barriers one group computes while the other loads: X: L0 | M0 | L1 | M1 ...  Y: -- | L0 | M0 | L1 ...
+// Phase order (token quarter, k-step): (0,0) (1,0) (1,1) (0,1): consecutive phases share the feature fragments or the
+// k-step, so the reads are 8, 4, 8, 4.  LDS hazards: every read is retired (lgkmcnt(0)) BEFORE the barrier that ends its
+// load part, a wave's own pieces are waited for (vmcnt(0)) in the load part of phase 3, i.e. before the barrier after
+// which the first wave reads the next k-tile; the stage refilled in phases 0-1 of k-tile t+1 was last read in phase 3 of
+// k-tile t, whose reads retired before the barrier in between — for either group.
+// Same LDS image, swizzle, persistent XCD-contiguous tile loop, next-tile prefetch and epilogue as variant 7; same
+// arithmetic and accumulation order: identical bits.
+#include "common.h"
+#include "gemm_epilogue.h"
+#include "../../include/moviigen_hip.h"
+
+#define V8_BM 256
+#define V8_BN 256
+#define V8_BK 64
+#define V8_THREADS 512
+#define V8_A_BYTES (V8_BM * V8_BK * 2)  // 32 KiB
+#define V8_W_BYTES (V8_BN * V8_BK * 2)  // 32 KiB
+#define V8_STAGE (V8_A_BYTES + V8_W_BYTES)
+
+typedef const __attribute__((address_space(1))) void* v8_gptr_t;
+typedef __attribute__((address_space(3))) void* v8_lptr_t;
+MG_DEV void v8_glds16(const void* g, void* l) { __builtin_amdgcn_global_load_lds((v8_gptr_t)g, (v8_lptr_t)l, 16, 0, 0); }
+
+template <int OFF>
+MG_DEV void v8_rd(bf16x8_t& dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
+}
+// four fragment reads of consecutive 16-row blocks (2 KiB apart) starting at block b0
+template <int B0>
+MG_DEV void v8_rd4(bf16x8_t (&f)[4], unsigned base) {
+    v8_rd<(B0 + 0) * 2048>(f[0], base);
+    v8_rd<(B0 + 1) * 2048>(f[1], base);
+    v8_rd<(B0 + 2) * 2048>(f[2], base);
+    v8_rd<(B0 + 3) * 2048>(f[3], base);
+}
+
+extern unsigned long long* g_gemm5_prof;    // gemm_bf16.hip: mg_gemm5_debug_profile
+
+// Wave priorities (s_setprio around the MFMA part, around the load part, static for the second-dispatched group) were
+// measured and make no difference here (profiles/r03i_gemm_v8_prio.log: all within 0.5 %): none is used.
+template <int EPI, bool PROF = false, bool PH2 = false>
+__global__ __launch_bounds__(V8_THREADS, 2) void gemm_bf16_v8_kernel(
+    const uint16_t* __restrict__ A, int64_t lda, const uint16_t* __restrict__ Wt, int64_t ldw,
+    const float* __restrict__ bias, int64_t M, int N, int K, void* __restrict__ out, int64_t ldo,
+    const float* __restrict__ gate, int tiles_m, int tiles_n, unsigned long long* __restrict__ prof) {
+    unsigned long long pt[5] = {0, 0, 0, 0, 0};
+    __shared__ __attribute__((aligned(16))) char smem[2 * V8_STAGE];
+
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int total = tiles_m * tiles_n;
+    const int q8 = total >> 3, r8 = total & 7, xcd = bid & 7;
+    const int xcd_first = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int xcd_count = q8 + (xcd < r8 ? 1 : 0);
+    const int per_iter = nwg >> 3;        // host guarantees nwg % 8 == 0
+    const int GM = 4;                     // 4 x 256 = a 1024-token band
+    const int per_group = GM * tiles_n;
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, r16 = lane & 15, G = lane >> 4;
+    const int wm = wave >> 2, wn = wave & 3;     // group X = wm 0 = waves 0-3, group Y = wm 1 = waves 4-7
+    const int srow = lane >> 3;
+    constexpr int NP = 8;                        // LDS-DMA duty: wave w stages rows [32w, 32w+32) of A (pieces 0-3) and of W (4-7)
+    const int prow0 = wave * 32;
+
+    auto tile_of = [&](int pos, int64_t& m0, int& n0) __attribute__((always_inline)) {
+        const int swz = xcd_first + pos;
+        const int group = swz / per_group;
+        const int first_m = group * GM;
+        const int gsz = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
+        const int in_g = swz - group * per_group;
+        m0 = (int64_t)(first_m + in_g % gsz) * V8_BM;
+        n0 = (in_g / gsz) * V8_BN;
+    };
+    const uint16_t* gp[NP];
+    auto set_pointers = [&](int64_t m0, int n0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int row = prow0 + (i & 3) * 8 + srow;
+            if (i < 4) {
+                int64_t am = m0 + row;
+                if (am > M - 1) am = M - 1;
+                gp[i] = A + am * lda + (((lane & 7) ^ ((row >> 1) & 7)) << 3);
+            } else {
+                int wr = n0 + row;
+                if (wr > N - 1) wr = N - 1;
+                gp[i] = Wt + (int64_t)wr * ldw + (((lane & 7) ^ ((row >> 1) & 7)) << 3);
+            }
+        }
+    };
+    auto piece_lds = [&](int p) __attribute__((always_inline)) {
+        return (p < 4 ? 0 : V8_A_BYTES) + (prow0 + (p & 3) * 8) * 128;
+    };
+
+    const int sw = (r16 >> 1) & 7;            // (row >> 1) & 7 of the lane's row in every 16-row block
+    const int t3 = G ^ sw;                    // chunk of k-step 0; k-step 1: t3 ^ 4
+    const unsigned lds0 = (unsigned)(uintptr_t)(v8_lptr_t)smem;
+    const int a_row_off = (wm * 128 + r16) * 128;
+    const int w_row_off = V8_A_BYTES + (wn * 64 + r16) * 128;
+    const int nk = K / V8_BK;
+
+    int pos = bid >> 3;
+    if (pos >= xcd_count) return;             // whole workgroup: no barrier is left waiting
+    int64_t m0;
+    int n0;
+    tile_of(pos, m0, n0);
+    set_pointers(m0, n0);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) v8_glds16(gp[i], smem + piece_lds(i));      // cold start of the FIRST tile only
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (PH2 && wm == 1) {     // two-phase form: group Y's pieces of k-tile 1 go out now, in the interval of X's first load part
+#pragma unroll
+        for (int i = 0; i < NP; ++i) v8_glds16(gp[i] + V8_BK, smem + V8_STAGE + piece_lds(i));
+    }
+    if (wm == 1) __builtin_amdgcn_s_barrier();          // group Y runs one barrier behind group X from here on
+    int gk = 0;                                   // k-tiles consumed so far by this workgroup: stage = gk & 1
+    for (;;) {
+        f32x4_t acc[4][8];       // [feature block of 16][token block of 16]
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        const int next_pos = pos + per_iter;
+        const bool has_next = next_pos < xcd_count;
+        int64_t m0n = m0;
+        int n0n = n0;
+        for (int kt = 0; kt < nk; ++kt, ++gk) {
+            int koff2 = (kt + 1) * V8_BK;
+            bool y_issue = true;
+            if (PH2 && wm == 1) {     // group Y refills the stage it is reading with k-tile kt + 2 (see the two-phase form below)
+                int kn = kt + 2;
+                if (kn >= nk) {
+                    kn -= nk;
+                    y_issue = has_next;
+                    if (has_next && kt == nk - 2) {
+                        tile_of(next_pos, m0n, n0n);
+                        set_pointers(m0n, n0n);
+                    }
+                }
+                koff2 = kn * V8_BK;
+            } else if (kt == nk - 1) {   // refill of the last k-tile: the first k-tile of the NEXT tile (or a redundant re-load)
+                koff2 = has_next ? 0 : kt * V8_BK;
+                if (has_next) {
+                    tile_of(next_pos, m0n, n0n);
+                    set_pointers(m0n, n0n);
+                }
+            }
+            char* lnext = smem + ((gk + 1) & 1) * V8_STAGE;
+            const unsigned lsb = lds0 + (gk & 1) * V8_STAGE;
+            const unsigned ab0 = lsb + a_row_off + (t3 << 4), wb0 = lsb + w_row_off + (t3 << 4);                 // k-step 0
+            const unsigned ab1 = lsb + a_row_off + ((t3 ^ 4) << 4), wb1 = lsb + w_row_off + ((t3 ^ 4) << 4);     // k-step 1
+            if (PH2) {
+                // Two phases per k-tile (one per 32-deep k-step): { 12 fragment reads ; barrier ; 32 MFMAs ; barrier } — half the
+                // barriers per MFMA of the four-phase form below.  With two 64 KiB stages a refill may start when BOTH groups
+                // have read the stage for the last time and must have landed before the first group reads it again: a window
+                // of four barrier intervals, which both groups use in full —
+                //   X (k-tile t = intervals 4t .. 4t+3): issues its 8 pieces of k-tile t+1 in the load part of k-step 0
+                //     (interval 4t: stage of t-1, last read by Y in 4t-1), awaits them after the MFMAs of k-step 1 (4t+3);
+                //   Y (one interval behind): issues its 8 pieces of k-tile t+2 into the stage it has just finished reading,
+                //     BETWEEN the MFMAs of k-step 1 of k-tile t (interval 4t+4), awaits them in the load part of k-step 1 of
+                //     k-tile t+1 (4t+7); X reads that stage from 4t+8.
+                // (Everything issued in k-step 0 and awaited in the next load part — two intervals — was measured: the
+                // wait is exposed, -3.5 %.)
+                bf16x8_t fw2[4], fa2[8];
+                char* lcur = smem + (gk & 1) * V8_STAGE;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const unsigned long long c0 = PROF ? __builtin_amdgcn_s_memtime() : 0;
+                    {
+                        bf16x8_t (&falo)[4] = *(bf16x8_t (*)[4])&fa2[0];
+                        bf16x8_t (&fahi)[4] = *(bf16x8_t (*)[4])&fa2[4];
+                        v8_rd4<0>(fw2, ks ? wb1 : wb0);
+                        v8_rd4<0>(falo, ks ? ab1 : ab0);
+                        v8_rd4<4>(fahi, ks ? ab1 : ab0);
+                    }
+                    if (ks == 0 && wm == 0) {
+#pragma unroll
+                        for (int p = 0; p < NP; ++p) v8_glds16(gp[p] + koff2, lnext + piece_lds(p));
+                    }
+                    if (ks == 1 && wm == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // Y: my pieces of k-tile t+1
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    const unsigned long long c1 = PROF ? __builtin_amdgcn_s_memtime() : 0;
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    const unsigned long long c2 = PROF ? __builtin_amdgcn_s_memtime() : 0;
+                    const bool ydma = ks == 1 && wm == 1 && y_issue;     // Y: one piece of k-tile t+2 behind every fourth MFMA
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw2[i], fa2[j], acc[i][j], 0, 0, 0);
+                            if (ks == 1 && (j & 3) == 1) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                if (ydma) v8_glds16(gp[i * 2 + (j >> 2)] + koff2, lcur + piece_lds(i * 2 + (j >> 2)));
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (ks == 1 && wm == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // X: my pieces of k-tile t+1
+                    const unsigned long long c3 = PROF ? __builtin_amdgcn_s_memtime() : 0;
+                    __builtin_amdgcn_s_barrier();
+                    if (PROF) {
+                        const unsigned long long c4 = __builtin_amdgcn_s_memtime();
+                        pt[0] += c1 - c0, pt[1] += c2 - c1, pt[2] += c3 - c2, pt[3] += c4 - c3, pt[4] += 1;
+                    }
+                }
+                continue;
+            }
+            bf16x8_t fa[4], fw[4];
+#pragma unroll
+            for (int ph = 0; ph < 4; ++ph) {
+                const int tq = (ph == 0 || ph == 3) ? 0 : 1;      // token quarter of this phase; k-step = ph >> 1
+                const unsigned long long c0 = PROF ? __builtin_amdgcn_s_memtime() : 0;
+                // ---- load part -------------------------------------------------------------------------------
+                if (ph == 0) { v8_rd4<0>(fw, wb0); v8_rd4<0>(fa, ab0); }
+                else if (ph == 1) v8_rd4<4>(fa, ab0);
+                else if (ph == 2) { v8_rd4<0>(fw, wb1); v8_rd4<4>(fa, ab1); }
+                else v8_rd4<0>(fa, ab1);
+                if (ph < 2) {
+#pragma unroll
+                    for (int p = 4 * ph; p < 4 * ph + 4; ++p) v8_glds16(gp[p] + koff2, lnext + piece_lds(p));
+                }
+                if (ph == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my pieces of the next k-tile have landed
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // my fragment reads are retired
+                const unsigned long long c1 = PROF ? __builtin_amdgcn_s_memtime() : 0;
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned long long c2 = PROF ? __builtin_amdgcn_s_memtime() : 0;
+                // ---- MFMA part -------------------------------------------------------------------------------
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj)
+                        acc[i][4 * tq + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fa[jj], acc[i][4 * tq + jj], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned long long c3 = PROF ? __builtin_amdgcn_s_memtime() : 0;
+                __builtin_amdgcn_s_barrier();
+                if (PROF) {
+                    const unsigned long long c4 = __builtin_amdgcn_s_memtime();
+                    pt[0] += c1 - c0, pt[1] += c2 - c1, pt[2] += c3 - c2, pt[3] += c4 - c3, pt[4] += 1;
+                }
+            }
+        }
+        // ---- epilogue (gemm_epilogue.h) of THIS tile; the next tile's first k-tile is already staged ----
+        mg_gemm_epilogue16<EPI, 4, 8>(acc, m0 + wm * 128, n0 + wn * 64, r16, G, M, N, bias, gate, out, ldo);
+        if (!has_next) break;
+        pos = next_pos;
+        m0 = m0n;
+        n0 = n0n;
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();          // group X's partner of group Y's last barrier
+    if (PROF && lane == 0 && prof) {      // per wave: {load part, wait at barrier 1, MFMA part, wait at barrier 2}, phases -> prof[wave * 5 ..]
+#pragma unroll
+        for (int i = 0; i < 5; ++i) atomicAdd(prof + wave * 5 + i, pt[i]);
+    }
+}
+
+int mg_gemm_v8_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_t ldw, const float* bias, int64_t M,
+                      int N, int K, int epilogue, void* out, int64_t ldo, const float* gate, int two_phase, hipStream_t st) {
+    int n_cu = mg_cu_count();
+    if (n_cu < 0) return MG_ERR_LAUNCH;
+    n_cu &= ~7;                                         // one workgroup per CU (128 KiB LDS), a multiple of the 8 XCDs
+    if (n_cu < 8) n_cu = 8;
+    const int64_t tiles_m64 = (M + V8_BM - 1) / V8_BM;
+    const int tiles_n = (N + V8_BN - 1) / V8_BN;
+    if (tiles_m64 * tiles_n > 0x7fffffffLL) return MG_ERR_SHAPE;
+    const int tiles_m = (int)tiles_m64;
+    const int total = tiles_m * tiles_n;
+    int nwg = n_cu;
+    if (total < nwg) nwg = (total + 7) & ~7;          // few tiles: one iteration, still a multiple of 8 (idle ones return)
+    if (K < 2 * V8_BK) two_phase = 0;                 // the two-phase form refills two k-tiles ahead
+    const dim3 grid((unsigned)nwg), block(V8_THREADS);
+    if (g_gemm5_prof && epilogue == MG_EPI_BIAS_BF16) {
+        if (two_phase)
+            hipLaunchKernelGGL((gemm_bf16_v8_kernel<MG_EPI_BIAS_BF16, true, true>), grid, block, 0, st, A, lda, Wt, ldw, bias, M, N,
+                               K, out, ldo, gate, tiles_m, tiles_n, g_gemm5_prof);
+        else
+            hipLaunchKernelGGL((gemm_bf16_v8_kernel<MG_EPI_BIAS_BF16, true, false>), grid, block, 0, st, A, lda, Wt, ldw, bias, M, N,
+                               K, out, ldo, gate, tiles_m, tiles_n, g_gemm5_prof);
+        return mg_check_launch();
+    }
+#define LAUNCH(E)                                                                                                            \
+    if (two_phase)                                                                                                           \
+        hipLaunchKernelGGL((gemm_bf16_v8_kernel<E, false, true>), grid, block, 0, st, A, lda, Wt, ldw, bias, M, N, K, out, ldo, \
+                           gate, tiles_m, tiles_n, nullptr);                                                                 \
+    else                                                                                                                     \
+        hipLaunchKernelGGL((gemm_bf16_v8_kernel<E, false, false>), grid, block, 0, st, A, lda, Wt, ldw, bias, M, N, K, out, ldo, \
+                           gate, tiles_m, tiles_n, nullptr)
+    switch (epilogue) {
+        case MG_EPI_BIAS_BF16: LAUNCH(MG_EPI_BIAS_BF16); break;
+        case MG_EPI_BIAS_GELU_BF16: LAUNCH(MG_EPI_BIAS_GELU_BF16); break;
+        case MG_EPI_GATE_RESID_F32: LAUNCH(MG_EPI_GATE_RESID_F32); break;
+        default: LAUNCH(MG_EPI_BIAS_F32); break;
+    }
+#undef LAUNCH
+    return mg_check_launch();
+}
