@@ -56,7 +56,7 @@ template <int EPI, bool PROF = false>
 __global__ __launch_bounds__(V8_THREADS, 2) void gemm_bf16_v8_kernel(
     const uint16_t* __restrict__ A, int64_t lda, const uint16_t* __restrict__ Wt, int64_t ldw,
     const float* __restrict__ bias, int64_t M, int N, int K, void* __restrict__ out, int64_t ldo,
-    const float* __restrict__ gate, int tiles_m, int tiles_n, unsigned long long* __restrict__ prof) {
+    const float* __restrict__ gate, int tiles_m, int tiles_n, int raster, unsigned long long* __restrict__ prof) {
     unsigned long long pt[5] = {0, 0, 0, 0, 0};
     __shared__ __attribute__((aligned(16))) char smem[2 * V8_STAGE];
 
@@ -66,8 +66,15 @@ __global__ __launch_bounds__(V8_THREADS, 2) void gemm_bf16_v8_kernel(
     const int xcd_first = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
     const int xcd_count = q8 + (xcd < r8 ? 1 : 0);
     const int per_iter = nwg >> 3;        // host guarantees nwg % 8 == 0
-    const int GM = 4;                     // 4 x 256 = a 1024-token band
+    // raster 0: XCD x owns a contiguous range of tile positions (bands of 4 row tiles, its 32 workgroups = 4 x 8 tiles).
+    // raster 1 (nwg == 256): the WHOLE chip works on one 16 x 16 super-tile per iteration — XCD x still owns a 4 x 8 block
+    // of it (rows 4(x&3).., columns 8(x>>2)..), so what one L2 sees is unchanged, but the A band of an XCD is also the band
+    // of the XCD four further and its 8 weight panels those of three others: the re-reads meet in the Infinity Cache
+    // instead of going to HBM, and consecutive iterations walk along N inside one 4096-token band.
+    const int GM = raster ? 16 : 4;
     const int per_group = GM * tiles_n;
+    const int slot = bid >> 3;
+    const int p256 = (8 * (xcd >> 2) + (slot >> 2)) * 16 + 4 * (xcd & 3) + (slot & 3);
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -78,7 +85,7 @@ __global__ __launch_bounds__(V8_THREADS, 2) void gemm_bf16_v8_kernel(
     const int prow0 = wave * 32;
 
     auto tile_of = [&](int pos, int64_t& m0, int& n0) __attribute__((always_inline)) {
-        const int swz = xcd_first + pos;
+        const int swz = raster ? pos * 256 + p256 : xcd_first + pos;
         const int group = swz / per_group;
         const int first_m = group * GM;
         const int gsz = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
@@ -113,8 +120,8 @@ __global__ __launch_bounds__(V8_THREADS, 2) void gemm_bf16_v8_kernel(
     const int w_row_off = V8_A_BYTES + (wn * 64 + r16) * 128;
     const int nk = K / V8_BK;
 
-    int pos = bid >> 3;
-    if (pos >= xcd_count) return;             // whole workgroup: no barrier is left waiting
+    int pos = raster ? 0 : bid >> 3;
+    if (raster ? p256 >= total : pos >= xcd_count) return;             // whole workgroup: no barrier is left waiting
     int64_t m0;
     int n0;
     tile_of(pos, m0, n0);
@@ -131,8 +138,8 @@ __global__ __launch_bounds__(V8_THREADS, 2) void gemm_bf16_v8_kernel(
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        const int next_pos = pos + per_iter;
-        const bool has_next = next_pos < xcd_count;
+        const int next_pos = raster ? pos + 1 : pos + per_iter;
+        const bool has_next = raster ? next_pos * 256 + p256 < total : next_pos < xcd_count;
         int64_t m0n = m0;
         int n0n = n0;
         for (int kt = 0; kt < nk; ++kt, ++gk) {
@@ -210,15 +217,18 @@ int mg_gemm_v8_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_
     const int total = tiles_m * tiles_n;
     int nwg = n_cu;
     if (total < nwg) nwg = (total + 7) & ~7;          // few tiles: one iteration, still a multiple of 8 (idle ones return)
+    // narrow outputs (N <= 7936: o / cross-q / cross-o / ffn.2) gain 3-4.5 % from the chip-wide raster, the wide ones (q|k|v, ffn.0)
+    // lose 1.5-2 % (profiles/r03o_gemm_raster.log): chosen by shape
+    const int raster = (nwg == 256 && tiles_n < 32) ? 1 : 0;
     const dim3 grid((unsigned)nwg), block(V8_THREADS);
     if (g_gemm5_prof && epilogue == MG_EPI_BIAS_BF16) {
         hipLaunchKernelGGL((gemm_bf16_v8_kernel<MG_EPI_BIAS_BF16, true>), grid, block, 0, st, A, lda, Wt, ldw, bias, M, N, K,
-                           out, ldo, gate, tiles_m, tiles_n, g_gemm5_prof);
+                           out, ldo, gate, tiles_m, tiles_n, raster, g_gemm5_prof);
         return mg_check_launch();
     }
 #define LAUNCH(E)                                                                                          \
     hipLaunchKernelGGL((gemm_bf16_v8_kernel<E, false>), grid, block, 0, st, A, lda, Wt, ldw, bias, M, N, K, out, ldo, \
-                       gate, tiles_m, tiles_n, nullptr)
+                       gate, tiles_m, tiles_n, raster, nullptr)
     switch (epilogue) {
         case MG_EPI_BIAS_BF16: LAUNCH(MG_EPI_BIAS_BF16); break;
         case MG_EPI_BIAS_GELU_BF16: LAUNCH(MG_EPI_BIAS_GELU_BF16); break;
