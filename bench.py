@@ -75,16 +75,17 @@ def _usable_cores():
     return max(1, min(n, 64))
 
 
-def vae_decode_flops(T, h, w):
+def vae_decode_flops(T, h, w, up_taps=9):
     """(total, attention) FLOPs of WanVAE.decode for a latent [16,T,h,w] (reference vae.py:367-472 layout,
-    SURVEY.md Appendix A): 1116.5 TF at (21,104,240), 639.2 TF at (21,90,160) — SURVEY §8(d)."""
+    SURVEY.md Appendix A): 1116.5 TF at (21,104,240), 639.2 TF at (21,90,160) — SURVEY §8(d).  up_taps = 4: what this
+    engine EXECUTES for the three convs behind a nearest-2x upsample (four 2x2 phase convs instead of one 3x3)."""
     px, F0, F1, F2 = h * w, T, 1 + 2 * (T - 1), 1 + 4 * (T - 1)
     res = lambda cin, cout: 27 * cin * cout + 27 * cout * cout + (cin * cout if cin != cout else 0)  # noqa: E731
     attn = 2 * px * px * 384 * F0
     mac = (16 * 16 + 27 * 16 * 384 + 2 * res(384, 384) + 384 * 1152 + 384 * 384 + 3 * res(384, 384)) * px * F0 + attn
-    mac += 3 * 384 * 768 * px * (F0 - 1) + (9 * 384 * 192 + res(192, 384) + 2 * res(384, 384)) * 4 * px * F1
-    mac += 3 * 384 * 768 * 4 * px * (F1 - 1) + (9 * 384 * 192 + 3 * res(192, 192)) * 16 * px * F2
-    mac += (9 * 192 * 96 + 3 * res(96, 96) + 27 * 96 * 3) * 64 * px * F2
+    mac += 3 * 384 * 768 * px * (F0 - 1) + (up_taps * 384 * 192 + res(192, 384) + 2 * res(384, 384)) * 4 * px * F1
+    mac += 3 * 384 * 768 * 4 * px * (F1 - 1) + (up_taps * 384 * 192 + 3 * res(192, 192)) * 16 * px * F2
+    mac += (up_taps * 192 * 96 + 3 * res(96, 96) + 27 * 96 * 3) * 64 * px * F2
     return 2 * mac, 2 * attn
 
 
@@ -411,10 +412,11 @@ def main():
                          'algorithmic_flops_per_launch': attn_flops},
         }
         if vae_s is not None:
-            fv = vae_decode_flops(*lat_shape[1:])[0]
-            line['vae_decode'] = {'seconds': vae_s, 'latent': list(lat_shape), 'tflops_fp32': fv / vae_s / 1e12,
-                                  'fp32_mfma_peak_tflops': PEAK_F32_MFMA / 1e12, 'frac': fv / vae_s / PEAK_F32_MFMA,
-                                  'algorithmic_tflop': fv / 1e12}
+            fv = vae_decode_flops(*lat_shape[1:])[0]                    # the reference's arithmetic
+            fx = vae_decode_flops(*lat_shape[1:], up_taps=4)[0]         # what the MFMAs execute (phase-decomposed up-convs)
+            line['vae_decode'] = {'seconds': vae_s, 'latent': list(lat_shape), 'tflops_fp32': fx / vae_s / 1e12,
+                                  'fp32_mfma_peak_tflops': PEAK_F32_MFMA / 1e12, 'frac': fx / vae_s / PEAK_F32_MFMA,
+                                  'algorithmic_tflop': fv / 1e12, 'executed_tflop': fx / 1e12}
         # HBM-side traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this same
         # command (tools/round_end_gpu.sh); the newest committed summary FOR THIS WORKLOAD is reported, never a guess
         if world == 1 and not args.layers:

@@ -312,6 +312,16 @@ int mg_vae_conv_f32(const float* x, const float* cache, int tc, int T, int H, in
                     const float* w, const float* bias, int Cout, int kt, int kh, int kw, int up2,
                     const float* residual, float* out, void* stream);
 
+/* The 3x3 conv behind a nearest-exact 2x upsample (Resample upsample2d/3d, vae.py:66-83,138-141) as FOUR 2x2 convs of the
+ * image itself, one per output parity (py, px): out[t][2y+py][2x+px] reads image rows {y-1, y} (py = 0) or {y, y+1}
+ * (py = 1), likewise along x — the 3x3 taps that land on the same image pixel are summed into one weight beforehand.
+ * 4/9 of the multiply-adds of mg_vae_conv_f32(up2 = 1) and no per-tap index arithmetic; results agree with it to fp32
+ * rounding of the weight sums (not bit for bit).  x [T][H][W][Cin], out [T][2H][2W][Cout], zero padding as the reference's.
+ * mg_vae_upconv_fold_weights_f32: w [Cout][1][3][3][Cin] -> wp [4 = 2 py + px][Cout][2][2][Cin] (once per checkpoint). */
+int mg_vae_upconv_fold_weights_f32(const float* w, int Cout, int Cin, float* wp, void* stream);
+int mg_vae_upconv_phases_f32(const float* x, int T, int H, int W, int Cin, const float* wp, const float* bias, int Cout,
+                             float* out, void* stream);
+
 /* RMS_norm over channels (F.normalize(x, dim=C) * sqrt(C) * gamma, vae.py:39-54), optional SiLU
  * (vae.py:193-197, 466-468).  x,out [rows][C] channels-last. */
 int mg_vae_rmsnorm_silu_f32(const float* x, const float* gamma, float* out, int64_t rows, int C,

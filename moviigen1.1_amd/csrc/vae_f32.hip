@@ -35,6 +35,7 @@ struct ConvArgs {
     const float* x; const float* cache; int tc; int T, H, W, Cin; int64_t ldx;
     const float* w; int64_t ldw; const float* bias; int Cout; int kt, kh, kw; int up2;
     const float* residual; float* out; int64_t ldo; int Ho, Wo; int64_t M; float out_scale;
+    int phases = 0; int64_t w_phase_stride = 0;      // phases: blockIdx.z = 2 py + px is one of the four 2x2 phase convolutions (below)
 };
 
 // Output epilogue shared by both conv kernels: lane (l31, g) owns voxel row m and, per cout block nb and quad rq, the four
@@ -42,8 +43,8 @@ struct ConvArgs {
 // row before any is used): one load at a time, hipcc puts an `s_waitcnt vmcnt(0)` behind every load — NB*4 serialized
 // HBM round trips per tile with the matrix pipe idle.
 template <int NB, int GRP>      // GRP = cout blocks whose loads are in flight together (register budget of the caller)
-MG_DEV void cv_epilogue(const ConvArgs& a, const f32x16_t (&acc)[NB], int64_t m, int n0, int g) {
-    if (m >= a.M) return;
+MG_DEV void cv_epilogue(const ConvArgs& a, const f32x16_t (&acc)[NB], int64_t m_in, int64_t m, int n0, int g) {
+    if (m_in >= a.M) return;      // m_in: the voxel of the conv grid, m: its row in out / residual
     const bool fullw = n0 + NB * 32 <= a.Cout;           // whole tile inside Cout: vector path without per-quad checks
 #pragma unroll
     for (int nb0 = 0; nb0 < NB; nb0 += GRP) {
@@ -98,6 +99,14 @@ __global__ __launch_bounds__(CV_THREADS) void vae_conv_kernel(const ConvArgs a) 
     const int lane = tid & 63, l31 = lane & 31, g = lane >> 5;
     const int64_t m0 = (int64_t)blockIdx.x * CV_BM;
     const int n0 = blockIdx.y * BN;
+    // Phase mode (mg_vae_upconv_phases_f32): "3x3 conv of the nearest-2x upsampled image" = four 2x2 convs of the image
+    // itself, one per output parity (py, px): output row 2y+py reads upsampled rows 2y+py-1 .. 2y+py+1 = image rows
+    // {y-1, y, y} (py = 0) or {y, y, y+1} (py = 1) — taps that share an image row share a pre-summed weight
+    // (mg_vae_upconv_fold_weights_f32).  The conv grid is the INPUT grid, the tap origin is (py-1, px-1) and the result is
+    // scattered to (2y+py, 2x+px): 4 instead of 9 taps per output, and the taps go through the cheap pointer path.
+    const int ph = a.phases ? (int)blockIdx.z : 0;
+    const int oy = a.phases ? (ph >> 1) - 1 : -(a.kh / 2), ox = a.phases ? (ph & 1) - 1 : -(a.kw / 2);
+    const float* const wbase = a.w + ph * a.w_phase_stride;
 
     // ---- gather bookkeeping: this thread stages rows (tid>>3)+32i, float4 column tid&7 -----------
     const int ch4 = tid & 7;
@@ -135,7 +144,7 @@ __global__ __launch_bounds__(CV_THREADS) void vae_conv_kernel(const ConvArgs a) 
     const float* const base_neg = a.cache ? a.cache : a.x;          // frames before the chunk: the cache, if any
     const int has_cache = a.cache != nullptr;
 #pragma unroll
-    for (int i = 0; i < NB; ++i) pw[i] = a.w + (int64_t)min(n0 + (tid >> 3) + 32 * i, a.Cout - 1) * a.ldw;   // rows >= Cout: never stored
+    for (int i = 0; i < NB; ++i) pw[i] = wbase + (int64_t)min(n0 + (tid >> 3) + 32 * i, a.Cout - 1) * a.ldw;   // rows >= Cout: never stored
     // Per row, once per tile: which temporal / vertical / horizontal tap offsets stay inside the tensor (bits dt | dy<<3 |
     // dx<<6); a tap is valid when its three bits are set.  For the convolutions without the folded 2x upsample the row
     // pointer of a tap is then `frame base of the row` (recomputed when dt changes: every kh*kw taps) + a WAVE-UNIFORM
@@ -150,7 +159,7 @@ __global__ __launch_bounds__(CV_THREADS) void vae_conv_kernel(const ConvArgs a) 
         const int valid = vt_[i] >= 0;                               // rows past M: every tap reads the zero page (never stored)
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            const int ti = vt_[i] + d - (a.kt - 1), yy = vy_[i] + d - a.kh / 2, xx = vx_[i] + d - a.kw / 2;
+            const int ti = vt_[i] + d - (a.kt - 1), yy = vy_[i] + d + oy, xx = vx_[i] + d + ox;
             mk |= (unsigned)(valid & (d < a.kt) & ((ti >= 0) | (has_cache & (a.tc + ti >= 0)))) << d;
             mk |= (unsigned)(valid & (d < a.kh) & (yy >= 0) & (yy < a.Ho)) << (3 + d);
             mk |= (unsigned)(valid & (d < a.kw) & (xx >= 0) & (xx < a.Wo)) << (6 + d);
@@ -170,7 +179,7 @@ __global__ __launch_bounds__(CV_THREADS) void vae_conv_kernel(const ConvArgs a) 
                     fbc[i] = (ti >= 0 ? a.x : base_neg) + (int64_t)max(vox, 0) * a.ldx;
                 }
             }
-            const int64_t off = (int64_t)((ld_dy - a.kh / 2) * a.W + (ld_dx - a.kw / 2)) * a.ldx;   // wave-uniform
+            const int64_t off = (int64_t)((ld_dy + oy) * a.W + (ld_dx + ox)) * a.ldx;   // wave-uniform
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const unsigned ok = (vmask[i] >> ld_dt) & (vmask[i] >> (3 + ld_dy)) & (vmask[i] >> (6 + ld_dx)) & 1u;
@@ -263,7 +272,16 @@ __global__ __launch_bounds__(CV_THREADS) void vae_conv_kernel(const ConvArgs a) 
         __syncthreads();
     }
 
-    cv_epilogue<NB, 1>(a, acc, m0 + wave * 32 + l31, n0, g);
+    const int64_t m_in = m0 + wave * 32 + l31;
+    int64_t m_out = m_in;
+    if (a.phases && m_in < a.M) {
+        const int64_t hw = (int64_t)a.H * a.W;
+        const int t = (int)(m_in / hw);
+        const int rem = (int)(m_in - (int64_t)t * hw);
+        const int y = rem / a.W, x = rem - y * a.W;
+        m_out = ((int64_t)t * 2 * a.H + 2 * y + (ph >> 1)) * (2 * a.W) + 2 * x + (ph & 1);
+    }
+    cv_epilogue<NB, 1>(a, acc, m_in, m_out, n0, g);
 }
 
 static int launch_conv(const ConvArgs& a, hipStream_t st) {
@@ -277,7 +295,7 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
     else if (a.Cout % 96 == 0) nb = 3;
     else nb = 4;
     const int bn = 32 * nb;
-    const dim3 grid((unsigned)tiles_m, (unsigned)((a.Cout + bn - 1) / bn)), block(CV_THREADS);
+    const dim3 grid((unsigned)tiles_m, (unsigned)((a.Cout + bn - 1) / bn), a.phases ? 4u : 1u), block(CV_THREADS);
     if (nb == 1) hipLaunchKernelGGL(vae_conv_kernel<1>, grid, block, 0, st, a);
     else if (nb == 3) hipLaunchKernelGGL(vae_conv_kernel<3>, grid, block, 0, st, a);
     else hipLaunchKernelGGL(vae_conv_kernel<4>, grid, block, 0, st, a);
@@ -302,6 +320,48 @@ extern "C" int mg_vae_conv_f32(const float* x, const float* cache, int tc, int T
     a.w = w; a.ldw = (int64_t)kt * kh * kw * Cin; a.bias = bias; a.Cout = Cout; a.kt = kt; a.kh = kh; a.kw = kw;
     a.up2 = up2 ? 1 : 0; a.residual = residual; a.out = out; a.ldo = Cout;
     a.Ho = up2 ? 2 * H : H; a.Wo = up2 ? 2 * W : W; a.M = (int64_t)T * a.Ho * a.Wo; a.out_scale = 1.f;
+    a.phases = 0; a.w_phase_stride = 0;
+    return launch_conv(a, (hipStream_t)stream);
+}
+
+// w [Cout][1][3][3][Cin] -> wp [4 phases = 2 py + px][Cout][2][2][Cin]: the taps of a 3x3 kernel that fall on the same image
+// pixel under the nearest-2x upsample, summed (py = 0: {w0 | w1 + w2}, py = 1: {w0 + w1 | w2}; the same along x)
+__global__ void upconv_fold_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin) {
+    const int64_t total = (int64_t)4 * Cout * 4 * Cin;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % Cin);
+        int64_t r = i / Cin;
+        const int dx = (int)(r & 1), dy = (int)((r >> 1) & 1);
+        r >>= 2;
+        const int co = (int)(r % Cout), ph = (int)(r / Cout);
+        const int py = ph >> 1, px = ph & 1;
+        const int y0 = py == 0 ? (dy == 0 ? 0 : 1) : (dy == 0 ? 0 : 2), y1 = py == 0 ? (dy == 0 ? 0 : 2) : (dy == 0 ? 1 : 2);
+        const int x0 = px == 0 ? (dx == 0 ? 0 : 1) : (dx == 0 ? 0 : 2), x1 = px == 0 ? (dx == 0 ? 0 : 2) : (dx == 0 ? 1 : 2);
+        float acc = 0.f;
+        for (int yy = y0; yy <= y1; ++yy)
+            for (int xx = x0; xx <= x1; ++xx) acc += w[(((int64_t)co * 3 + yy) * 3 + xx) * Cin + ci];
+        wp[i] = acc;
+    }
+}
+
+extern "C" int mg_vae_upconv_fold_weights_f32(const float* w, int Cout, int Cin, float* wp, void* stream) {
+    if (!w || !wp) return MG_ERR_ARG;
+    if (Cout <= 0 || Cin <= 0) return MG_ERR_SHAPE;
+    hipLaunchKernelGGL(upconv_fold_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, w, wp, Cout, Cin);
+    return mg_check_launch();
+}
+
+extern "C" int mg_vae_upconv_phases_f32(const float* x, int T, int H, int W, int Cin, const float* wp, const float* bias,
+                                        int Cout, float* out, void* stream) {
+    if (!x || !wp || !out) return MG_ERR_ARG;
+    if (T <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 3) || Cout <= 0) return MG_ERR_SHAPE;
+    if (((uintptr_t)x & 15) || ((uintptr_t)wp & 15) || ((uintptr_t)out & 15) || (bias && ((uintptr_t)bias & 15))) return MG_ERR_SHAPE;
+    if ((int64_t)T * 4 * H * W > 0x7fffffffLL) return MG_ERR_SHAPE;      // output voxels stay 32-bit like every other conv's
+    ConvArgs a;
+    a.x = x; a.cache = nullptr; a.tc = 0; a.T = T; a.H = H; a.W = W; a.Cin = Cin; a.ldx = Cin;
+    a.w = wp; a.ldw = (int64_t)4 * Cin; a.bias = bias; a.Cout = Cout; a.kt = 1; a.kh = 2; a.kw = 2; a.up2 = 0;
+    a.residual = nullptr; a.out = out; a.ldo = Cout; a.Ho = H; a.Wo = W; a.M = (int64_t)T * H * W; a.out_scale = 1.f;
+    a.phases = 1; a.w_phase_stride = (int64_t)Cout * 4 * Cin;
     return launch_conv(a, (hipStream_t)stream);
 }
 

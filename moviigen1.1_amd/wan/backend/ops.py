@@ -207,6 +207,26 @@ def vae_conv(x, w, bias, out, kt, kh, kw, cache=None, up2=False, residual=None):
     return out
 
 
+def vae_upconv_fold_weights(w):
+    """w [Cout,1,3,3,Cin] (the conv behind a nearest-2x upsample) -> [4,Cout,2,2,Cin]: one 2x2 kernel per output parity."""
+    _chk(w, torch.float32, 'w')
+    Cout, kt, kh, kw, Cin = w.shape
+    if (kt, kh, kw) != (1, 3, 3):
+        raise ValueError(f'the phase decomposition is defined for 1x3x3 kernels, got {kt}x{kh}x{kw}')
+    wp = torch.empty(4, Cout, 2, 2, Cin, dtype=torch.float32, device=w.device)
+    lib.call('mg_vae_upconv_fold_weights_f32', _p(w), Cout, Cin, _p(wp), _st())
+    return wp
+
+
+def vae_upconv_phases(x, wp, bias, out):
+    """x [T,H,W,Cin]; wp from vae_upconv_fold_weights; out [T,2H,2W,Cout] = conv3x3(nearest-2x(x))."""
+    for n, t in (('x', x), ('wp', wp), ('bias', bias), ('out', out)):
+        _chk(t, torch.float32, n)
+    T, H, W, Cin = x.shape
+    lib.call('mg_vae_upconv_phases_f32', _p(x), T, H, W, Cin, _p(wp), _p(bias), wp.shape[1], _p(out), _st())
+    return out
+
+
 def vae_rmsnorm_silu(x, gamma, out, do_silu=True):
     C = x.shape[-1]
     lib.call('mg_vae_rmsnorm_silu_f32', _p(x), _p(gamma), _p(out), x.numel() // C, C, int(do_silu), _st())

@@ -34,7 +34,13 @@ class WanVAE_:
     """decoder-side container: parameters keyed by the reference state_dict names, repacked for
     the channels-last kernels ([Cout,Cin,kt,kh,kw] -> [Cout,kt,kh,kw,Cin])."""
 
-    def __init__(self, state_dict, z_dim=16, device='cuda'):
+    def __init__(self, state_dict, z_dim=16, device='cuda', upconv='phases'):
+        """upconv: how the 3x3 conv behind a nearest-2x upsample runs — 'phases' = four 2x2 convs of the image with
+        pre-summed taps (4/9 of the multiply-adds; default), 'gather' = the 3x3 conv reading through the upsample (the two
+        agree to fp32 rounding of the weight sums; kept as the cross-check)."""
+        if upconv not in ('phases', 'gather'):
+            raise ValueError(f"upconv must be 'phases' or 'gather', got {upconv!r}")
+        self.upconv = upconv
         self.z_dim = z_dim
         self.device = torch.device(device)
         self.P = {}
@@ -127,7 +133,14 @@ class WanVAE_:
                 idx[0] += 1
                 T, H, W, C2 = y.shape
                 x = ops.vae_time_interleave(y, self._new(2 * T, H, W, C2 // 2))
-        return self._conv(pre + 'resample.1', x, up2=True)
+        if self.upconv == 'gather':
+            return self._conv(pre + 'resample.1', x, up2=True)
+        name = pre + 'resample.1'
+        wp = self.P.get(name + '.phases')
+        if wp is None:                                   # folded once per checkpoint
+            wp = self.P[name + '.phases'] = ops.vae_upconv_fold_weights(self.P[name + '.weight'])
+        T, H, W, _ = x.shape
+        return ops.vae_upconv_phases(x, wp, self.P[name + '.bias'], self._new(T, 2 * H, 2 * W, wp.shape[1]))
 
     # ---- the decoder as a list of stages (each owns a contiguous range of feat_cache slots) ---------
     def _stages(self):
@@ -169,7 +182,9 @@ class WanVAE_:
             names = [k for k in self.P if k.startswith(pre) and k.endswith('weight') and self.P[k].dim() == 5]
             c = 0
             for k in names:
-                scale = 4 if 'resample' in k else 1                  # the 2x nearest upsample is folded into this conv
+                scale = 1
+                if 'resample' in k:                                   # the conv runs at the upsampled resolution: 9 taps
+                    scale = 4 if self.upconv == 'gather' else 16 / 9  # per output, or 4 as phase convs
                 f = 2 * frames if ('resample' in k and (pre + 'time_conv.weight') in self.P) else frames
                 c += self.P[k].numel() * px * scale * f
             if kind == 'attn':
@@ -276,7 +291,7 @@ def partition_costs(costs, parts):
 class WanVAE:
 
     def __init__(self, z_dim=16, vae_pth='cache/vae_step_411000.pth', dtype=torch.float, device='cuda',
-                 state_dict=None):
+                 state_dict=None, upconv='phases'):
         if dtype not in (torch.float, torch.float32):
             raise NotImplementedError('the reference decodes in fp32 (vae.py:623,658); so does this engine')
         self.dtype = dtype
@@ -284,7 +299,7 @@ class WanVAE:
         if state_dict is None:
             logging.info(f'loading {vae_pth}')
             state_dict = torch.load(vae_pth, map_location='cpu', weights_only=True)
-        self.model = WanVAE_(state_dict, z_dim=z_dim, device=device)
+        self.model = WanVAE_(state_dict, z_dim=z_dim, device=device, upconv=upconv)
         self.mean, self.std = torch.tensor(_MEAN[:z_dim]), torch.tensor(_STD[:z_dim])
         self.scale = [self.mean, 1.0 / self.std]
 

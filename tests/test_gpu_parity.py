@@ -777,6 +777,40 @@ def test_vae_conv_shapes(dev, cin, cout, T, H, W, tc, up2):
     assert ((got - ref).abs().max() / ref.abs().max()).item() < 1e-5
 
 
+@pytest.mark.parametrize('cin,cout,T,H,W', [(8, 12, 2, 5, 7), (64, 96, 1, 16, 24), (192, 96, 3, 9, 11), (384, 192, 2, 13, 6), (20, 3, 1, 4, 4)])
+def test_vae_upconv_phases(dev, cin, cout, T, H, W):
+    """conv3x3(nearest-2x(x)) as four 2x2 phase convs with pre-summed taps (mg_vae_upconv_phases_f32, what WanVAE.decode
+    runs) against the 3x3 conv that reads through the upsample (mg_vae_conv_f32 up2 = 1) — the whole output — and against
+    an fp64 evaluation on sampled voxels incl. the four corners (zero padding of the UPSAMPLED image); the folded weights
+    against their definition."""
+    from wan.backend import ops
+    gen = torch.Generator(device=dev).manual_seed(cin * 5 + cout)
+    x = torch.randn(T, H, W, cin, device=dev, generator=gen)
+    w = torch.randn(cout, 1, 3, 3, cin, device=dev, generator=gen) / math.sqrt(9 * cin)
+    b = torch.randn(cout, device=dev, generator=gen)
+    wp = ops.vae_upconv_fold_weights(w)
+    w64 = w.double().cpu()[:, 0]                                    # [cout, 3, 3, cin]
+    rows = {0: ((0,), (1, 2)), 1: ((0, 1), (2,))}                   # parity -> 3x3 taps behind each of the two image taps
+    for py in (0, 1):
+        for px in (0, 1):
+            for dy in (0, 1):
+                for dx in (0, 1):
+                    ref = sum(w64[:, yy, xx] for yy in rows[py][dy] for xx in rows[px][dx])
+                    assert (wp[2 * py + px, :, dy, dx].double().cpu() - ref).abs().max().item() < 1e-6
+    got = torch.full((T, 2 * H, 2 * W, cout), float('nan'), device=dev)
+    ops.vae_upconv_phases(x, wp, b, got)
+    assert torch.isfinite(got).all().item()                         # every output voxel of every phase written
+    old = torch.empty(T, 2 * H, 2 * W, cout, device=dev)
+    ops.vae_conv(x, w, b, old, 1, 3, 3, up2=True)
+    assert ((got - old).abs().max() / old.abs().max()).item() < 1e-5
+    Ho, Wo = 2 * H, 2 * W
+    pts = [(0, 0, 0), (T - 1, Ho - 1, Wo - 1), (0, Ho - 1, 0), (T - 1, 0, Wo - 1), (T // 2, Ho // 2, Wo // 2), (0, 1, Wo - 2),
+           (0, Ho - 2, 1)]
+    ref = _conv_ref_f64(x, None, w, b, pts, True)
+    sel = torch.stack([got[t, y, xx] for (t, y, xx) in pts]).double().cpu()
+    assert ((sel - ref).abs().max() / ref.abs().max()).item() < 1e-5
+
+
 def test_vae_conv_rejects_large_kernel_extents(dev):
     """the tile gather's per-tap validity masks hold extents up to 3: a 5x5 (or 5-frame) kernel is refused, not mis-computed."""
     from wan.backend import lib, ops
