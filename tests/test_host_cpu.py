@@ -170,6 +170,24 @@ def test_vae_stage_partition():
     assert partition_costs([7], 1) == [0, 1]
 
 
+def test_vae_upconv_option_host_side():
+    """WanVAE_'s `upconv` keyword: validated at construction, and the layer-pipelined decode weighs the up-conv stages by
+    what they execute (9 taps at 4x the pixels through the upsample, 16/9 as phase convs)."""
+    from wan.modules.vae import WanVAE_
+    P = W.make_vae_params(8, 1)
+    with pytest.raises(ValueError):
+        WanVAE_(P, device='cpu', upconv='bilinear')
+    ph, ga = WanVAE_(P, device='cpu'), WanVAE_(P, device='cpu', upconv='gather')
+    assert ph.upconv == 'phases' and ga.upconv == 'gather'
+    cp, cg = ph.stage_costs(8, 8), ga.stage_costs(8, 8)
+    kinds = [k for k, _, _ in ph._stages()]
+    assert len(cp) == len(cg) == len(kinds)
+    for k, a, b in zip(kinds, cp, cg):
+        assert (a < b) if k == 'up' else (a == b)
+    w_up = [(b - a) for k, a, b in zip(kinds, cp, cg) if k == 'up']
+    assert all(d > 0 for d in w_up)
+
+
 def _launcher():
     import importlib.util
     import os
@@ -268,6 +286,10 @@ def test_bench_flop_formulas():
     tot, attn = b.vae_decode_flops(21, 104, 240)
     assert abs(tot / 1e12 - 1116.5) < 0.1 and abs(attn / 1e12 - 20.1) < 0.05
     assert abs(b.vae_decode_flops(21, 90, 160)[0] / 1e12 - 639.2) < 0.1
+    # executed by this engine: the three convs behind a 2x upsample as four 2x2 phase convs = 4/9 of their taps
+    ex = b.vae_decode_flops(21, 104, 240, up_taps=4)[0]
+    up = 2 * (384 * 192 * 4 * 41 + 384 * 192 * 16 * 81 + 192 * 96 * 64 * 81) * 104 * 240      # FLOPs per tap of the three convs
+    assert abs((tot - ex) - 5 * up) < 1e6 and abs(ex / 1e12 - 1065.8) < 0.1
     assert b.WORKLOADS['1080p'][:3] == (1920, 832, 81)
 
 
