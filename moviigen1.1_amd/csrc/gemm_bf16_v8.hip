@@ -67,14 +67,16 @@ __global__ __launch_bounds__(V8_THREADS, 2) void gemm_bf16_v8_kernel(
     const int xcd_count = q8 + (xcd < r8 ? 1 : 0);
     const int per_iter = nwg >> 3;        // host guarantees nwg % 8 == 0
     // raster 0: XCD x owns a contiguous range of tile positions (bands of 4 row tiles, its 32 workgroups = 4 x 8 tiles).
-    // raster 1 (nwg == 256): the WHOLE chip works on one 16 x 16 super-tile per iteration — XCD x still owns a 4 x 8 block
-    // of it (rows 4(x&3).., columns 8(x>>2)..), so what one L2 sees is unchanged, but the A band of an XCD is also the band
-    // of the XCD four further and its 8 weight panels those of three others: the re-reads meet in the Infinity Cache
-    // instead of going to HBM, and consecutive iterations walk along N inside one 4096-token band.
-    const int GM = raster ? 16 : 4;
+    // rasters 1 / 2 / 3 (nwg == 256): the WHOLE chip works on one super-tile of 16 x 16 / 32 x 8 / 8 x 32 output tiles per
+    // iteration — XCD x still owns a 4 x 8 block of it (an XR x 8/XR grid of XCDs), so what one L2 sees is unchanged, but
+    // the A band of an XCD is also the band of 8/XR - 1 others and its 8 weight panels those of XR - 1 others: the re-reads
+    // meet in the Infinity Cache instead of going to HBM, and consecutive iterations walk along N inside one band.
+    const int XR = raster == 2 ? 8 : raster == 3 ? 2 : 4;      // XCD grid XR x (8 / XR) inside a super-tile of 4 XR rows x 64 / XR columns
+    const int SR = 4 * XR;
+    const int GM = raster ? SR : 4;
     const int per_group = GM * tiles_n;
     const int slot = bid >> 3;
-    const int p256 = (8 * (xcd >> 2) + (slot >> 2)) * 16 + 4 * (xcd & 3) + (slot & 3);
+    const int p256 = (8 * (xcd / XR) + (slot >> 2)) * SR + 4 * (xcd % XR) + (slot & 3);
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -217,9 +219,11 @@ int mg_gemm_v8_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_
     const int total = tiles_m * tiles_n;
     int nwg = n_cu;
     if (total < nwg) nwg = (total + 7) & ~7;          // few tiles: one iteration, still a multiple of 8 (idle ones return)
-    // narrow outputs (N <= 7936: o / cross-q / cross-o / ffn.2) gain 3-4.5 % from the chip-wide raster, the wide ones (q|k|v, ffn.0)
-    // lose 1.5-2 % (profiles/r03o_gemm_raster.log): chosen by shape
-    const int raster = (nwg == 256 && tiles_n < 32) ? 1 : 0;
+    // Raster by shape (profiles/r03o_gemm_raster.log, r03r_gemm_rasters.log; M = 131040, TFLOP/s for rasters 0 / 1 / 2 / 3):
+    //   q|k|v 1295 / 1267 / 1299 / 1231, ffn.0 1214 / 1186 / 1219 / 1184            -> wide outputs stay on raster 0
+    //   o (K 5120, gated residual) 1076 / 1129 / 1063 / 1153, cross-q 1236 / 1286 / 1261 / 1284   -> raster 3 (8 x 32)
+    //   ffn.2 (K 13824) 1250 / 1250 / 1245 / 1238                                   -> raster 1 (16 x 16)
+    const int raster = (nwg == 256 && tiles_n < 32) ? (K > 8192 ? 1 : 3) : 0;
     const dim3 grid((unsigned)nwg), block(V8_THREADS);
     if (g_gemm5_prof && epilogue == MG_EPI_BIAS_BF16) {
         hipLaunchKernelGGL((gemm_bf16_v8_kernel<MG_EPI_BIAS_BF16, true>), grid, block, 0, st, A, lda, Wt, ldw, bias, M, N, K,

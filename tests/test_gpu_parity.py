@@ -128,12 +128,12 @@ def test_gemm_epilogues(dev, M, N, K, epi):
 
 
 @pytest.mark.parametrize('M,N,K', [(700, 520, 256), (257, 132, 64), (1030, 1284, 640), (4200, 4100, 128), (9000, 2304, 64),
-                                   (2100, 8448, 128)])
+                                   (2100, 8448, 128), (4200, 4100, 8256)])
 def test_gemm_tile_variants_agree(dev, M, N, K):
     """the tile schedules (128x128, 256x128, 256x256 with one wave per SIMD: one tile per workgroup, and the persistent
     tile loop — the last three shapes have more tiles than CUs, so its workgroups iterate: two with < 32 tile columns = the
-    chip-wide 16x16 super-tile raster of variant 8, incl. a partial band, one with 33 = the per-XCD band raster) give the
-    same bits, ragged edges included."""
+    chip-wide 8x32 super-tile raster of variant 8, incl. a partial band, one with 33 = the per-XCD band raster, one narrow with
+    K > 8192 = the 16x16 super-tile raster) give the same bits, ragged edges included."""
     from wan.backend import lib, ops
     a = W.randn((M, K), 16).bfloat16().to(dev)
     w = (W.randn((N, K), 17) * 0.05).bfloat16().to(dev)
