@@ -322,6 +322,14 @@ int mg_vae_upconv_fold_weights_f32(const float* w, int Cout, int Cin, float* wp,
 int mg_vae_upconv_phases_f32(const float* x, int T, int H, int W, int Cin, const float* wp, const float* bias, int Cout,
                              float* out, void* stream);
 
+/* Arithmetic of the VAE convolutions (mg_vae_conv_f32, mg_vae_upconv_phases_f32) — a process-global OPT-IN switch, not
+ * thread-safe, default 0:
+ *   0 = exact: v_mfma_f32_32x32x2_f32, bitwise an fmaf chain — the reference's fp32 arithmetic (vae.py:623,658);
+ *   1 = split bf16 x 3: every fp32 operand as hi + lo bf16 (16 mantissa bits), W_hi.X_hi + W_hi.X_lo + W_lo.X_hi on the
+ *       bf16 MFMA with fp32 accumulation: ~1e-5 relative to mode 0 per convolution, NOT the reference's arithmetic and never
+ *       what bench.py measures.  The attention block's two GEMMs stay exact. */
+void mg_vae_set_mode(int mode);
+
 /* RMS_norm over channels (F.normalize(x, dim=C) * sqrt(C) * gamma, vae.py:39-54), optional SiLU
  * (vae.py:193-197, 466-468).  x,out [rows][C] channels-last. */
 int mg_vae_rmsnorm_silu_f32(const float* x, const float* gamma, float* out, int64_t rows, int C,

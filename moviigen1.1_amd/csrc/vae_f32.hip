@@ -90,7 +90,13 @@ MG_DEV void cv_epilogue(const ConvArgs& a, const f32x16_t (&acc)[NB], int64_t m_
     }
 }
 
-template <int NB>
+// FAST = the opt-in split-bf16 mode (mg_vae_set_mode(1)): every fp32 operand is split once, when its tile is staged, into
+// hi = bf16(x) and lo = bf16(x - hi) — 16 mantissa bits — and the product runs as W_hi.X_hi + W_hi.X_lo + W_lo.X_hi on
+// v_mfma_f32_32x32x16_bf16 with the same fp32 accumulators (the dropped lo.lo term is 2^-18 of a product): 6 MFMAs of 32
+// cycles per 32-channel chunk and cout block instead of 16 of 64.  LDS rows keep their 144 bytes: 32 hi (64 B) | 32 lo
+// (64 B) | 16 B pad — fragment reads of 16 consecutive rows still land on 16 distinct 16-byte slots (9 r mod 16).
+// NOT the reference's arithmetic: results agree with the exact mode to ~1e-5 relative (test_vae_fast_mode), never the default.
+template <int NB, bool FAST = false>
 __global__ __launch_bounds__(CV_THREADS) void vae_conv_kernel(const ConvArgs a) {
     constexpr int BN = 32 * NB;
     __shared__ __attribute__((aligned(16))) float smem[2 * (CV_BM + BN) * CV_LDS];
@@ -224,9 +230,25 @@ __global__ __launch_bounds__(CV_THREADS) void vae_conv_kernel(const ConvArgs a) 
             }
         }
     };
+    auto split_store = [&](float* row, const float4& v) __attribute__((always_inline)) {      // FAST: 4 fp32 -> 4 hi + 4 lo bf16
+        const float h0 = round_bf(v.x), h1 = round_bf(v.y), h2 = round_bf(v.z), h3 = round_bf(v.w);
+        uint2 hi, lo;
+        hi.x = pack_bf2(v.x, v.y); hi.y = pack_bf2(v.z, v.w);
+        lo.x = pack_bf2(v.x - h0, v.y - h1); lo.y = pack_bf2(v.z - h2, v.w - h3);
+        char* r = (char*)row;
+        *(uint2*)(r + ch4 * 8) = hi;
+        *(uint2*)(r + 64 + ch4 * 8) = lo;
+    };
     auto store_chunk = [&](int buf) __attribute__((always_inline)) {
         float* sa = smem + buf * (CV_BM + BN) * CV_LDS;
         float* sw = sa + CV_BM * CV_LDS;
+        if (FAST) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) split_store(sa + ((tid >> 3) + 32 * i) * CV_LDS, ra[i]);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) split_store(sw + ((tid >> 3) + 32 * i) * CV_LDS, rw[i]);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) *(float4*)(sa + ((tid >> 3) + 32 * i) * CV_LDS + ch4 * 4) = ra[i];
 #pragma unroll
@@ -250,6 +272,23 @@ __global__ __launch_bounds__(CV_THREADS) void vae_conv_kernel(const ConvArgs a) 
         __builtin_amdgcn_sched_barrier(0);
         const float* sa = smem + (kc & 1) * (CV_BM + BN) * CV_LDS + (wave * 32 + l31) * CV_LDS + g * 4;
         const float* sw = smem + (kc & 1) * (CV_BM + BN) * CV_LDS + CV_BM * CV_LDS + l31 * CV_LDS + g * 4;
+        if (FAST) {
+            // lane (l31, g): row l31, k = 16 s + 8 g .. + 7 of k-step s: 16 bytes at byte 32 s + 16 g of the hi plane (lo: + 64)
+            const char* xa = (const char*)(sa - g * 4) + g * 16;
+            const char* wa = (const char*)(sw - g * 4) + g * 16;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8_t xh = *(const bf16x8_t*)(xa + ks * 32), xl = *(const bf16x8_t*)(xa + 64 + ks * 32);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const bf16x8_t wh = *(const bf16x8_t*)(wa + nb * 32 * CV_LDS * 4 + ks * 32);
+                    const bf16x8_t wl = *(const bf16x8_t*)(wa + nb * 32 * CV_LDS * 4 + 64 + ks * 32);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh, acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, acc[nb], 0, 0, 0);
+                }
+            }
+        } else
 #pragma unroll
         for (int k8 = 0; k8 < 4; ++k8) {
             const float4 xa = *(const float4*)(sa + k8 * 8);
@@ -284,7 +323,10 @@ __global__ __launch_bounds__(CV_THREADS) void vae_conv_kernel(const ConvArgs a) 
     cv_epilogue<NB, 1>(a, acc, m_in, m_out, n0, g);
 }
 
-static int launch_conv(const ConvArgs& a, hipStream_t st) {
+static int g_vae_mode = 0;      // 0 = exact fp32 MFMA (the reference's arithmetic), 1 = split-bf16 x 3 (opt-in fast mode)
+extern "C" void mg_vae_set_mode(int mode) { g_vae_mode = mode == 1 ? 1 : 0; }
+
+static int launch_conv(const ConvArgs& a, hipStream_t st, bool allow_fast = true) {
     if ((int64_t)(a.T > a.tc ? a.T : a.tc) * a.H * a.W > 0x7fffffffLL) return MG_ERR_SHAPE;   // 32-bit voxel index in the gather
     if (a.kt * a.kh * a.kw > 1 && a.Cin > 1024) return MG_ERR_SHAPE;                           // padding taps index the zero page by channel
     const int64_t tiles_m = (a.M + CV_BM - 1) / CV_BM;
@@ -296,9 +338,15 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
     else nb = 4;
     const int bn = 32 * nb;
     const dim3 grid((unsigned)tiles_m, (unsigned)((a.Cout + bn - 1) / bn), a.phases ? 4u : 1u), block(CV_THREADS);
-    if (nb == 1) hipLaunchKernelGGL(vae_conv_kernel<1>, grid, block, 0, st, a);
-    else if (nb == 3) hipLaunchKernelGGL(vae_conv_kernel<3>, grid, block, 0, st, a);
-    else hipLaunchKernelGGL(vae_conv_kernel<4>, grid, block, 0, st, a);
+    if (g_vae_mode == 1 && allow_fast) {
+        if (nb == 1) hipLaunchKernelGGL((vae_conv_kernel<1, true>), grid, block, 0, st, a);
+        else if (nb == 3) hipLaunchKernelGGL((vae_conv_kernel<3, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((vae_conv_kernel<4, true>), grid, block, 0, st, a);
+        return mg_check_launch();
+    }
+    if (nb == 1) hipLaunchKernelGGL((vae_conv_kernel<1, false>), grid, block, 0, st, a);
+    else if (nb == 3) hipLaunchKernelGGL((vae_conv_kernel<3, false>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((vae_conv_kernel<4, false>), grid, block, 0, st, a);
     return mg_check_launch();
 }
 
@@ -490,13 +538,13 @@ extern "C" int mg_vae_attn_f32(const float* qkv, float* out, int frames, int64_t
             a.w = base + C; a.ldw = 3 * C; a.bias = nullptr; a.Cout = (int)L; a.kt = a.kh = a.kw = 1; a.up2 = 0;
             a.residual = nullptr; a.out = S; a.ldo = Lp; a.Ho = 1; a.Wo = (int)nq; a.M = nq;
             a.out_scale = 1.f / sqrtf((float)C);
-            int rc = launch_conv(a, st);
+            int rc = launch_conv(a, st, false);     // the attention block's two GEMMs stay exact in either mode
             if (rc) return rc;
             hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)nq), dim3(256), 0, st, S, L, Lp);
             // out[nq][C] = P[nq][Lp] . vT[C][Lp]^T   (padding columns are zero on both sides)
             a.x = S; a.ldx = Lp; a.Cin = (int)Lp; a.w = vT; a.ldw = Lp; a.Cout = C; a.out = out + ((int64_t)f * L + q0) * C;
             a.ldo = C; a.out_scale = 1.f;
-            rc = launch_conv(a, st);
+            rc = launch_conv(a, st, false);
             if (rc) return rc;
         }
     }

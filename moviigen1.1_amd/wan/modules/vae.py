@@ -34,13 +34,16 @@ class WanVAE_:
     """decoder-side container: parameters keyed by the reference state_dict names, repacked for
     the channels-last kernels ([Cout,Cin,kt,kh,kw] -> [Cout,kt,kh,kw,Cin])."""
 
-    def __init__(self, state_dict, z_dim=16, device='cuda', upconv='phases'):
+    def __init__(self, state_dict, z_dim=16, device='cuda', upconv='phases', mode='exact'):
         """upconv: how the 3x3 conv behind a nearest-2x upsample runs — 'phases' = four 2x2 convs of the image with
         pre-summed taps (4/9 of the multiply-adds; default), 'gather' = the 3x3 conv reading through the upsample (the two
         agree to fp32 rounding of the weight sums; kept as the cross-check)."""
         if upconv not in ('phases', 'gather'):
             raise ValueError(f"upconv must be 'phases' or 'gather', got {upconv!r}")
+        if mode not in ('exact', 'bf16x3'):
+            raise ValueError(f"mode must be 'exact' (the reference's fp32 arithmetic) or 'bf16x3', got {mode!r}")
         self.upconv = upconv
+        self.mode = mode          # 'bf16x3': opt-in split-bf16 convolutions (~1e-5 relative per conv), see mg_vae_set_mode
         self.z_dim = z_dim
         self.device = torch.device(device)
         self.P = {}
@@ -199,6 +202,16 @@ class WanVAE_:
     @torch.no_grad()
     def decode(self, z, chunks=None):
         """z [16,T,h,w] -> [3, 1+4(T-1), 8h, 8w] fp32 clamped to [-1,1]."""
+        if self.mode == 'bf16x3':                 # process-global switch of the library: set for this decode only
+            from ..backend import lib
+            lib.load().mg_vae_set_mode(1)
+            try:
+                return self._decode(z, chunks)
+            finally:
+                lib.load().mg_vae_set_mode(0)
+        return self._decode(z, chunks)
+
+    def _decode(self, z, chunks=None):
         z = z.to(self.device, torch.float32).contiguous()
         C, T, H, W = z.shape
         x = ops.vae_latent_in(z, self.mean, self.inv_std, self._new(T, H, W, C))
@@ -291,7 +304,7 @@ def partition_costs(costs, parts):
 class WanVAE:
 
     def __init__(self, z_dim=16, vae_pth='cache/vae_step_411000.pth', dtype=torch.float, device='cuda',
-                 state_dict=None, upconv='phases'):
+                 state_dict=None, upconv='phases', mode='exact'):
         if dtype not in (torch.float, torch.float32):
             raise NotImplementedError('the reference decodes in fp32 (vae.py:623,658); so does this engine')
         self.dtype = dtype
@@ -299,7 +312,7 @@ class WanVAE:
         if state_dict is None:
             logging.info(f'loading {vae_pth}')
             state_dict = torch.load(vae_pth, map_location='cpu', weights_only=True)
-        self.model = WanVAE_(state_dict, z_dim=z_dim, device=device, upconv=upconv)
+        self.model = WanVAE_(state_dict, z_dim=z_dim, device=device, upconv=upconv, mode=mode)
         self.mean, self.std = torch.tensor(_MEAN[:z_dim]), torch.tensor(_STD[:z_dim])
         self.scale = [self.mean, 1.0 / self.std]
 

@@ -814,6 +814,56 @@ def test_vae_upconv_phases(dev, cin, cout, T, H, W):
     assert ((sel - ref).abs().max() / ref.abs().max()).item() < 1e-5
 
 
+def test_vae_fast_mode(dev, golden):
+    """the opt-in split-bf16 x 3 mode of the VAE convolutions (mg_vae_set_mode(1); WanVAE(mode='bf16x3')) against the exact
+    mode: single convolutions (3x3x3 with cache and residual, channel tails, Cout = 3, the phase up-conv) to 1e-4 of the
+    largest output, a whole small decode to 2e-3 absolute on [-1, 1] video values; the switch is restored."""
+    import wan
+    from wan.backend import lib, ops
+    h = lib.load()
+    gen = torch.Generator(device=dev).manual_seed(11)
+    try:
+        for (cin, cout, Tn, H, Wd, tc) in [(96, 96, 3, 12, 20, 2), (384, 192, 2, 9, 7, 1), (20, 3, 2, 6, 6, 0), (192, 384, 1, 8, 8, 0)]:
+            x = torch.randn(Tn, H, Wd, cin, device=dev, generator=gen)
+            cache = torch.randn(tc, H, Wd, cin, device=dev, generator=gen) if tc else None
+            w = torch.randn(cout, 3, 3, 3, cin, device=dev, generator=gen) / math.sqrt(27 * cin)
+            b = torch.randn(cout, device=dev, generator=gen)
+            res = torch.randn(Tn, H, Wd, cout, device=dev, generator=gen)
+            outs = []
+            for mode in (0, 1):
+                h.mg_vae_set_mode(mode)
+                o = torch.full((Tn, H, Wd, cout), float('nan'), device=dev)
+                ops.vae_conv(x, w, b, o, 3, 3, 3, cache=cache, residual=res)
+                outs.append(o)
+            assert torch.isfinite(outs[1]).all().item()
+            assert not torch.equal(outs[0], outs[1])                    # the fast kernel really ran
+            assert ((outs[0] - outs[1]).abs().max() / outs[0].abs().max()).item() < 1e-4
+        x = torch.randn(2, 10, 14, 192, device=dev, generator=gen)
+        wp = ops.vae_upconv_fold_weights(torch.randn(96, 1, 3, 3, 192, device=dev, generator=gen) / math.sqrt(9 * 192))
+        b = torch.randn(96, device=dev, generator=gen)
+        outs = []
+        for mode in (0, 1):
+            h.mg_vae_set_mode(mode)
+            outs.append(ops.vae_upconv_phases(x, wp, b, torch.empty(2, 20, 28, 96, device=dev)))
+        assert ((outs[0] - outs[1]).abs().max() / outs[0].abs().max()).item() < 1e-4
+    finally:
+        h.mg_vae_set_mode(0)
+    P = W.make_vae_params(8, 1)
+    z = torch.randn(16, 3, 8, 8, generator=torch.Generator().manual_seed(3)).to(dev)
+    exact = wan.modules.WanVAE(state_dict=P, device=dev).model.decode(z)
+    fast = wan.modules.WanVAE(state_dict=P, device=dev, mode='bf16x3').model.decode(z)
+    again = wan.modules.WanVAE(state_dict=P, device=dev).model.decode(z)
+    assert torch.equal(exact, again)                                    # the mode does not leak into the next decode
+    assert not torch.equal(exact, fast) and (exact - fast).abs().max().item() < 2e-3
+    # against the reference's own outputs (the goldens of test_vae_decode_vs_reference), at the mode's stated tolerance
+    for dim, t in ((8, 3), (32, 2)):
+        g = golden(f'g5_vae_d{dim}_t{t}')
+        out = wan.modules.WanVAE(state_dict=W.make_vae_params(dim, 1), device=dev, mode='bf16x3').decode([T(g['z']).to(dev)])[0]
+        err = scale_err(out, g['video'])
+        print(f'bf16x3 decode vs reference golden d{dim} t{t}: scale_err {err:.3e}')
+        assert err < 1e-4          # measured 7.1e-5 (d8) / 4.3e-5 (d32): the same bound the exact mode is held to
+
+
 def test_vae_conv_rejects_large_kernel_extents(dev):
     """the tile gather's per-tap validity masks hold extents up to 3: a 5x5 (or 5-frame) kernel is refused, not mis-computed."""
     from wan.backend import lib, ops
