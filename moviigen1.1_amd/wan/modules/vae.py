@@ -13,6 +13,7 @@ bias and the residual add folded in; RMS_norm+SiLU and the per-frame d=384 atten
 kernels as well.  The chunked decode with its 2-frame feature cache follows the reference
 protocol (vae.py:101-141,202-220,423-472,544-568) slot for slot.
 """
+import contextlib
 import logging
 import os
 
@@ -202,14 +203,21 @@ class WanVAE_:
     @torch.no_grad()
     def decode(self, z, chunks=None):
         """z [16,T,h,w] -> [3, 1+4(T-1), 8h, 8w] fp32 clamped to [-1,1]."""
-        if self.mode == 'bf16x3':                 # process-global switch of the library: set for this decode only
-            from ..backend import lib
-            lib.load().mg_vae_set_mode(1)
-            try:
-                return self._decode(z, chunks)
-            finally:
-                lib.load().mg_vae_set_mode(0)
-        return self._decode(z, chunks)
+        with self._mode_scope():
+            return self._decode(z, chunks)
+
+    @contextlib.contextmanager
+    def _mode_scope(self):
+        """the library's arithmetic switch is process-global: 'bf16x3' is set for the duration of one decode only."""
+        if self.mode != 'bf16x3':
+            yield
+            return
+        from ..backend import lib
+        lib.load().mg_vae_set_mode(1)
+        try:
+            yield
+        finally:
+            lib.load().mg_vae_set_mode(0)
 
     def _decode(self, z, chunks=None):
         z = z.to(self.device, torch.float32).contiguous()
@@ -249,6 +257,12 @@ class WanVAE_:
         P, rank = dist.get_world_size(group), dist.get_rank(group)
         if P == 1:
             return self.decode(z)
+        with self._mode_scope():
+            return self._decode_pipelined(z, group, P, rank)
+
+    def _decode_pipelined(self, z, group, P, rank):
+        import torch.distributed as dist
+        from ..distributed.ulysses import p2p_recv, p2p_send
         z = z.to(self.device, torch.float32).contiguous()
         C, T, H, W = z.shape
         stages = self._stages()
