@@ -103,17 +103,6 @@ int mg_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw,
                  const float* bias, int64_t M, int N, int K, int epilogue, void* out,
                  int64_t ldo, const float* gate, void* stream);
 
-/* Tile schedule of mg_gemm_bf16 (same results bit for bit) — a process-global MEASUREMENT / TEST switch, not part of
- * the drop-in contract and not thread-safe; the default (0) selects by shape (8 for M > 256 and N > 128, else 2 / 1):
- * 8 = 256x256x64 tile, v_mfma_f32_16x16x32_bf16, persistent loop (one workgroup per CU; the first k-tile of the next
- *     tile is fetched during the last k-tile of the current one), EIGHT waves in two ping-pong groups: in every interval
- *     between two barriers one group issues 16 MFMAs per wave while its SIMD partners read fragments and issue LDS-DMA;
- * 7 = the same tile and loop with 4 waves = ONE per SIMD (128x128 each), LDS-DMA pieces and fragment reads spread
- *     between the wave's own MFMAs (A/B partner);
- * 2 = 256x128x64 tile, 8 waves, 3-stage LDS ring with counted vmcnt (M > 128, else 1);
- * 1 = 128x128x64 tile, 4 waves, 2 stages. */
-void mg_gemm_set_variant(int variant);
-
 /* softmax(q k^T * scale) v, non-causal, keys >= Lk masked; bf16 in/out, fp32 accumulate,
  * head_dim 128.  Replaces flash_attn_varlen_func as called from
  * wan/modules/attention.py:96-127 (self-attention model.py:146-151, k_lens=seq_lens;
@@ -222,14 +211,6 @@ int mg_attn_fwd_bf16_generic(const uint16_t* q, int64_t ldq, const uint16_t* k, 
                              const uint16_t* v, int64_t ldv, uint16_t* o, int64_t ldo, int64_t Lq,
                              int64_t Lk, int heads, int head_dim, float scale, void* stream);
 
-/* Kernel behind mg_attn_fwd_bf16_hd128* and the matching K row order of mg_pack_kv_bf16 — a process-global
- * MEASUREMENT / TEST switch (same math in both), not part of the drop-in contract and not thread-safe:
- * 0 = "m16" (default): 4 waves x 64 queries, one wave per SIMD, v_mfma_f32_16x16x32_bf16, zero-reference softmax,
- *     software-pipelined in 32-key units (csrc/attn_hd128_m16.hip);
- * 3 = "w64": the round-2 kernel (32x32x16 MFMA, per-row softmax reference; csrc/attn_hd128_w64.hip).
- * Other values select 0.  Pack and attend under the same setting. */
-void mg_attn_set_variant(int variant);
-
 /* ------------------------------------------------------------------------------------------
  * DiT — small fp32 pieces (time embedding, head, patch gather, latent algebra)
  * ---------------------------------------------------------------------------------------- */
@@ -310,7 +291,7 @@ int mg_t5_attn_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v, int
  * MG_ERR_SHAPE. */
 int mg_vae_conv_f32(const float* x, const float* cache, int tc, int T, int H, int W, int Cin,
                     const float* w, const float* bias, int Cout, int kt, int kh, int kw, int up2,
-                    const float* residual, float* out, void* stream);
+                    const float* residual, float* out, int mode, void* stream);
 
 /* The 3x3 conv behind a nearest-exact 2x upsample (Resample upsample2d/3d, vae.py:66-83,138-141) as FOUR 2x2 convs of the
  * image itself, one per output parity (py, px): out[t][2y+py][2x+px] reads image rows {y-1, y} (py = 0) or {y, y+1}
@@ -320,15 +301,16 @@ int mg_vae_conv_f32(const float* x, const float* cache, int tc, int T, int H, in
  * mg_vae_upconv_fold_weights_f32: w [Cout][1][3][3][Cin] -> wp [4 = 2 py + px][Cout][2][2][Cin] (once per checkpoint). */
 int mg_vae_upconv_fold_weights_f32(const float* w, int Cout, int Cin, float* wp, void* stream);
 int mg_vae_upconv_phases_f32(const float* x, int T, int H, int W, int Cin, const float* wp, const float* bias, int Cout,
-                             float* out, void* stream);
+                             float* out, int mode, void* stream);
 
-/* Arithmetic of the VAE convolutions (mg_vae_conv_f32, mg_vae_upconv_phases_f32) — a process-global OPT-IN switch, not
- * thread-safe, default 0:
- *   0 = exact: v_mfma_f32_32x32x2_f32, bitwise an fmaf chain — the reference's fp32 arithmetic (vae.py:623,658);
- *   1 = split bf16 x 3: every fp32 operand as hi + lo bf16 (16 mantissa bits), W_hi.X_hi + W_hi.X_lo + W_lo.X_hi on the
- *       bf16 MFMA with fp32 accumulation: ~1e-5 relative to mode 0 per convolution, NOT the reference's arithmetic and never
- *       what bench.py measures.  The attention block's two GEMMs stay exact. */
-void mg_vae_set_mode(int mode);
+/* `mode` of mg_vae_conv_f32 / mg_vae_upconv_phases_f32 — the arithmetic of THAT call (ABI 7: an argument, not a
+ * process-global switch; anything else returns MG_ERR_ARG):
+ *   MG_VAE_EXACT  = v_mfma_f32_32x32x2_f32, bitwise an fmaf chain — the reference's fp32 arithmetic (vae.py:623,658);
+ *   MG_VAE_BF16X3 = split bf16 x 3: every fp32 operand as hi + lo bf16 (16 mantissa bits), W_hi.X_hi + W_hi.X_lo + W_lo.X_hi
+ *       on the bf16 MFMA with fp32 accumulation: ~1e-5 relative to the exact mode per convolution, NOT the reference's
+ *       arithmetic, opt-in (WanVAE(mode='bf16x3')) and never what bench.py measures.  mg_vae_attn_f32 is always exact. */
+#define MG_VAE_EXACT 0
+#define MG_VAE_BF16X3 1
 
 /* RMS_norm over channels (F.normalize(x, dim=C) * sqrt(C) * gamma, vae.py:39-54), optional SiLU
  * (vae.py:193-197, 466-468).  x,out [rows][C] channels-last. */
@@ -371,9 +353,28 @@ int mg_vae_time_interleave_f32(const float* x, int T, int64_t HW, int C, float* 
  * csrc/tools/selftest.cpp and tools/ to take s_memtime breakdowns of the hot loops and to force kernel
  * schedules for A/B measurements.  All are process-global switches; passing NULL / 0 restores the default.
  * ---------------------------------------------------------------------------------------- */
+/* Tile schedule of mg_gemm_bf16 (same results bit for bit) — a process-global MEASUREMENT / TEST switch, not part of
+ * the drop-in contract and not thread-safe; the default (0) selects by shape (8 for M > 256 and N > 128, else 2 / 1):
+ * 8 = 256x256x64 tile, v_mfma_f32_16x16x32_bf16, persistent loop (one workgroup per CU; the first k-tile of the next
+ *     tile is fetched during the last k-tile of the current one), EIGHT waves in two ping-pong groups: in every interval
+ *     between two barriers one group issues 16 MFMAs per wave while its SIMD partners read fragments and issue LDS-DMA;
+ * 7 = the same tile and loop with 4 waves = ONE per SIMD (128x128 each), LDS-DMA pieces and fragment reads spread
+ *     between the wave's own MFMAs (A/B partner);
+ * 2 = 256x128x64 tile, 8 waves, 3-stage LDS ring with counted vmcnt (M > 128, else 1);
+ * 1 = 128x128x64 tile, 4 waves, 2 stages. */
+void mg_gemm_set_variant(int variant);
+
+/* Kernel behind mg_attn_fwd_bf16_hd128* and the matching K row order of mg_pack_kv_bf16 — a process-global
+ * MEASUREMENT / TEST switch (same math in both), not part of the drop-in contract and not thread-safe:
+ * 0 = "m16" (default): 4 waves x 64 queries, one wave per SIMD, v_mfma_f32_16x16x32_bf16, first-tile softmax reference in the MFMA's C operand,
+ *     software-pipelined in 32-key units (csrc/attn_hd128_m16.hip);
+ * 3 = "w64": the round-2 kernel (32x32x16 MFMA, per-row softmax reference; csrc/attn_hd128_w64.hip).
+ * Other values select 0.  Pack and attend under the same setting. */
+void mg_attn_set_variant(int variant);
+
 void mg_attn_w64_profile(unsigned long long* dev_buf);     /* both attention kernels: 4 waves x {fence, step A, step B, iterations} */
 void mg_attn_w64_debug(int flags);                         /* bit 0: keep the pipelined result of flagged blocks (no exact pass) */
-void mg_attn_w64_flag_counter(unsigned* dev_counter);      /* both kernels: *dev_counter += query blocks redone by the exact pass */
+void mg_attn_w64_flag_counter(unsigned* dev_counter);      /* dev_counter[2]: [0] += query blocks whose pipelined pass flagged (m16: repeated with swept row maxima; w64: redone by the exact loop), [1] += m16 blocks that went on to the exact loop */
 void mg_gemm_debug_profile(unsigned long long* dev_buf);   /* GEMM variants 1/2: 8 waves x {wait+barrier, stage issue, MFMA, k-tiles} */
 void mg_gemm5_debug_profile(unsigned long long* dev_buf);   /* GEMM variant 7: 4 waves x {wait+barrier, k-step 0, k-step 1, k-tiles}; 8: 8 waves x {load, wait, MFMA, wait, phases} (64 words) */
 

@@ -19,15 +19,23 @@
 //       of the V tile image (8 consecutive keys of one d): 8 V fragments (d blocks) x 4 query blocks = 32 MFMAs.
 //   O^T: lane (qi, G) holds d = 16*db + 4G + r of its query: four consecutive d per d block, 8-byte stores.
 //
-// Softmax: ZERO reference.  A common factor 2^-m per row cancels in O / l, so the running maximum of the textbook
-// online softmax only has to keep p representable — and P is bf16, O^T and l are fp32: p = 2^(s*c) with NO maximum,
-// no rescale and no branch in the hot loop; a final row sum outside [2^-60, 2^90] (or inf / NaN; l only grows, so one
-// test at the end covers every partial sum) flags the workgroup, which then redoes its block with the plain exact loop
-// (true running maximum).  With the DiT's RMS-normed q and k the scores are bounded by |q||k|/sqrt(d) and nothing flags.
+// Softmax: FIXED per-row reference, folded into the MFMA.  A common factor 2^-m per row cancels in O / l, so the running
+// maximum of the textbook online softmax only has to keep p representable — and P is bf16 (fp32's exponent range), O^T
+// and l are fp32.  The reference of a row is the maximum of its scores against the FIRST key tile (64 keys, computed in
+// the prologue anyway); -m_ref is the C operand of the first of the four MFMAs of every S^T accumulator (where round 3
+// had the literal 0: the quad of a query block lives in 4 VGPRs, 16 per lane for the four blocks), so a score leaves
+// the matrix pipe already relative to its row's reference: p = 2^(s*c) with no maximum, no subtraction, no rescale and
+// no branch in the hot loop.  The reference is that maximum RAISED by 2^64: the row's true maximum is at least the first
+// tile's, so l >= 2^-64 by construction (every term that matters stays a normal fp32 / bf16 number) and only grows,
+// inf / NaN are sticky, so ONE test of the final row sum — at most 2^90 — covers every partial sum: a row passes unless
+// some later key beats the first tile's best by more than 154 bits = 106 natural units.  A workgroup that fails the test sweeps its keys
+// once for the TRUE row maxima (S^T only, K double-buffered) and repeats the same pipelined pass with those as the
+// reference (then l is in [1, Lk] whatever the logits are); only inf / NaN scores still fail and take the plain exact
+// loop, which also serves rows shorter than three full tiles.
 // SCALED = false (mg_attn_fwd_bf16_hd128_prescaled, what WanModel.forward uses): q already carries c = scale*log2(e)
 // (mg_rmsnorm_rope_bf16 out_scale: the factor enters before q's one rounding to bf16), a score IS its exponent and the
 // softmax costs exp + add + half a cvt_pk per score.  SCALED = true (any q, any scale): one v_mul more per score, q is
-// used as given (no second rounding).
+// used as given (no second rounding); the reference is kept in raw score units either way.
 #include <type_traits>
 #include "common.h"
 #include "../../include/moviigen_hip.h"
@@ -55,6 +63,7 @@ struct M16State {
     f32x4_t ot[8][4];      // O^T [d block][query block]             (AGPRs: builtin MFMAs)
     f32x4_t st[2][2][4];   // S^T [unit kb][key block a/b][query block]  (arch VGPRs: inline-asm MFMAs)
     bf16x8_t pf[2][4];     // P   [unit kb][query block]: keys 8G..8G+7 of the unit
+    f32x4_t mq[4];         // -m_ref of the lane's query in block n, four copies: C operand of an accumulator's first MFMA
     float m_run[4], l_run[4];
     int bad;
 };
@@ -69,8 +78,8 @@ MG_DEV void m16_wait() {
 }
 // S^T accumulators live in ARCH VGPRs (the softmax reads them with VALU instructions): inline asm with "v" operands,
 // as in w64.  A block is written by groups 0-3 (a) / 4-7 (b) of a step and first read by the NEXT step's softmax.
-MG_DEV void m16_mfma_s0(f32x4_t& acc, const bf16x8_t& a, const bf16x8_t& b) {       // acc = a.b
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b));
+MG_DEV void m16_mfma_s0(f32x4_t& acc, const bf16x8_t& a, const bf16x8_t& b, const f32x4_t& c) {       // acc = a.b + c
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=&v"(acc) : "v"(a), "v"(b), "v"(c));
 }
 MG_DEV void m16_mfma_s(f32x4_t& acc, const bf16x8_t& a, const bf16x8_t& b) {        // acc += a.b
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
@@ -115,7 +124,7 @@ MG_DEV void m16_softmax_exact(M16State& s, float c) {
     }
 }
 
-// softmax of unit KB against the fixed zero reference (prologue): p = 2^s
+// softmax of unit KB whose scores are already relative to the row references (prologue): p = 2^s
 template <int KB>
 MG_DEV void m16_softmax_zero(M16State& s, float c) {
 #pragma unroll
@@ -132,13 +141,13 @@ MG_DEV void m16_softmax_zero(M16State& s, float c) {
         for (int e = 0; e < 4; ++e) w[e] = pack_bf2(p[2 * e], p[2 * e + 1]);
         s.pf[KB][n] = m16_bf(w);
         s.l_run[n] += psum;
-        s.m_run[n] = 0.f;
     }
 }
 
-// accumulator start of S^T for a ragged tile: -1e30 on the key rows >= lim (the MFMAs add K.Q^T to it)
+// accumulator start of S^T for a ragged tile: -1e30 on the key rows >= lim, else `base` of the query block (0 or the
+// row reference); the MFMAs add K.Q^T to it
 template <int KB>
-MG_DEV void m16_mask_init(M16State& s, int lim, int G) {
+MG_DEV void m16_mask_init(M16State& s, int lim, int G, const f32x4_t (&base)[4]) {
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
@@ -146,7 +155,7 @@ MG_DEV void m16_mask_init(M16State& s, int lim, int G) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = KB * 32 + G * 8 + blk * 4 + r;
-                s.st[KB][blk][n][r] = key >= lim ? -1e30f : 0.f;
+                s.st[KB][blk][n][r] = key >= lim ? -1e30f : base[n][0];
             }
 }
 
@@ -204,7 +213,7 @@ MG_DEV void m16_step(M16State& s, const bf16x8_t (&qf)[4][4], bf16x8_t (&kf)[4],
     };
     auto S = [&](int i, int n) __attribute__((always_inline)) {
         const int blk = i >> 2, c = i & 3, r = i & 3;
-        if (SMODE == 1 && c == 0) m16_mfma_s0(s.st[KB][blk][n], kf[r], qf[n][c]);
+        if (SMODE == 1 && c == 0) m16_mfma_s0(s.st[KB][blk][n], kf[r], qf[n][c], s.mq[n]);
         else if (SMODE == 2 && c == 0) m16_mfma_s_after_valu(s.st[KB][blk][n], kf[r], qf[n][c]);
         else if (SMODE != 0) m16_mfma_s(s.st[KB][blk][n], kf[r], qf[n][c]);
     };
@@ -389,10 +398,11 @@ __global__ __launch_bounds__(M16_THREADS, 1) void attn_hd128_m16_kernel(
         m16_rd<m16_koff(1)>(kf[1], ak);
         m16_rd<m16_voff(1)>(vf[1], av);
     };
-    // bare S^T of one unit (prologue / exact loop): 32 MFMAs, plain loads
+    const f32x4_t zero4[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    // bare S^T of one unit (prologue / reference sweep / exact loop): 32 MFMAs, plain loads, RAW scores
     auto bare_S = [&](auto kbc, int slot, int lim) __attribute__((always_inline)) {
         constexpr int KB = decltype(kbc)::value;
-        if (lim < 64) m16_mask_init<KB>(s, lim, G);
+        if (lim < 64) m16_mask_init<KB>(s, lim, G, zero4);
         else {
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk)
@@ -422,21 +432,79 @@ __global__ __launch_bounds__(M16_THREADS, 1) void attn_hd128_m16_kernel(
     using KB0 = std::integral_constant<int, 0>;
     using KB1 = std::integral_constant<int, 1>;
 
-    // ------------------------------------------------------------------------------------------
-    // pipelined pass.  Iteration t = steps u = 2t (S(t,1) | P.V(t-1,1) | softmax S(t,0)) and
-    // u = 2t+1 (S(t+1,0) | P.V(t,0) | softmax S(t,1)); tile t in slot t % 3.  Needs >= 3 FULL
-    // tiles to have a steady state; shorter or all-ragged rows go straight to the exact loop.
-    // ------------------------------------------------------------------------------------------
     bool exact_pass = nfull < 3;
     if (!exact_pass) {
+    for (int attempt = 0;; ++attempt) {
+        // per-row maximum of the RAW scores in s.st[0..1] (the 64 keys of one tile), folded into mx
+        auto tile_max = [&](float (&mx)[4]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                float a = fmaxf(fmaxf(s.st[0][0][n][0], s.st[0][0][n][1]), fmaxf(s.st[0][0][n][2], s.st[0][0][n][3]));
+                float b = fmaxf(fmaxf(s.st[0][1][n][0], s.st[0][1][n][1]), fmaxf(s.st[0][1][n][2], s.st[0][1][n][3]));
+                float c2 = fmaxf(fmaxf(s.st[1][0][n][0], s.st[1][0][n][1]), fmaxf(s.st[1][0][n][2], s.st[1][0][n][3]));
+                float d2 = fmaxf(fmaxf(s.st[1][1][n][0], s.st[1][1][n][1]), fmaxf(s.st[1][1][n][2], s.st[1][1][n][3]));
+                mx[n] = fmaxf(mx[n], fmaxf(fmaxf(a, b), fmaxf(c2, d2)));
+            }
+        };
+        auto set_reference = [&](const float (&mx)[4], float above) __attribute__((always_inline)) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {       // a query's keys are spread over the four G lanes
+                float m = fmaxf(mx[n], __shfl_xor(mx[n], 16, 64));
+                m = fmaxf(m, __shfl_xor(m, 32, 64)) + above;
+                s.mq[n] = (f32x4_t){-m, -m, -m, -m};
+            }
+        };
+        if (attempt) {
+            // ------------------------------------------------------------------------------------------
+            // reference sweep (only after a flagged pass): TRUE row maxima.  S^T of every tile, K tiles
+            // double-buffered in slots 0 / 1, one barrier per tile, no V, no exponentials.
+            // ------------------------------------------------------------------------------------------
+            float mx[4] = {-1e30f, -1e30f, -1e30f, -1e30f};
+#pragma unroll
+            for (int n = 0; n < 4; ++n) dma_k(0, 0, n);
+            for (int t = 0; t < T; ++t) {
+                fence();                        // K(t) landed; everyone is past S(t-1): slot (t+1)&1 is free
+                if (t + 1 < T) {
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) dma_k(t + 1, (t + 1) & 1, n);
+                }
+                const int lim = t == T - 1 ? last_lim : 64;
+                bare_S(KB0{}, t & 1, lim);
+                bare_S(KB1{}, t & 1, lim);
+                tile_max(mx);
+            }
+            set_reference(mx, 0.f);
+            __syncthreads();                    // the last S reads are done before the pass below refills slots 0 / 1
+            reset();
+        }
+        // ------------------------------------------------------------------------------------------
+        // pipelined pass.  Iteration t = steps u = 2t (S(t,1) | P.V(t-1,1) | softmax S(t,0)) and
+        // u = 2t+1 (S(t+1,0) | P.V(t,0) | softmax S(t,1)); tile t in slot t % 3.  Needs >= 3 FULL
+        // tiles to have a steady state; shorter or all-ragged rows go straight to the exact loop.
+        // ------------------------------------------------------------------------------------------
 #pragma unroll
         for (int n = 0; n < 4; ++n) dma_k(0, 0, n), dma_v(0, 0, n), dma_k(1, 1, n);
         fence();
 #pragma unroll
         for (int n = 0; n < 4; ++n) dma_k(2, 2, n), dma_v(1, 1, n);     // iteration 0's refill
         bare_S(KB0{}, 0, 64);
-        m16_softmax_zero<0>(s, c_log2);
         bare_S(KB1{}, 0, 64);
+        if (attempt == 0) {
+            // first attempt: reference = the row's maximum over tile 0, RAISED by 2^64.  The true row maximum is at least
+            // tile 0's, so the largest term of a row is at least 2^-64 (every term that matters stays a normal fp32 /
+            // bf16 number) and the headroom above grows to 2^(90+64): the pass is good for rows whose best key beats
+            // the best of the first 64 by up to 154 bits = 106 natural units
+            float mx[4] = {-1e30f, -1e30f, -1e30f, -1e30f};
+            tile_max(mx);
+            set_reference(mx, c_log2 > 1e-20f ? 64.f / c_log2 : 0.f);       // (raw score units: an exponent is score * c)
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)          // tile 0 was computed raw: make it relative like every later tile
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) s.st[kb][blk][n] += s.mq[n];
+        m16_softmax_zero<0>(s, c_log2);
         // step u = 1: S(1,0) | P.V(0,0) | softmax S(0,1)
         prefetch(k_addr(1, 0), v_addr(0, 0));
         m16_step<0, 1, true, true, SCALED>(s, qf, kf, vf, k_addr(1, 0), v_addr(0, 0), k_addr(1, 1), v_addr(0, 1), c_log2, M16NoDma());
@@ -478,11 +546,11 @@ __global__ __launch_bounds__(M16_THREADS, 1) void attn_hd128_m16_kernel(
         m16_step<1, 1, true, true, SCALED>(s, qf, kf, vf, k_addr(s1, 1), v_addr(s0, 1), k_addr(s2, 0), v_addr(s1, 0), c_log2, M16NoDma());
         if (t + 1 < T) {
             // u = 2t+1 with the masked start for S(t+1,0)
-            m16_mask_init<0>(s, last_lim, G);
+            m16_mask_init<0>(s, last_lim, G, s.mq);
             m16_step<0, 2, true, true, SCALED>(s, qf, kf, vf, k_addr(s2, 0), v_addr(s1, 0), k_addr(s2, 1), v_addr(s1, 1), c_log2, M16NoDma());
             fence();                    // V(t+1) landed
             // u = 2t+2: S(t+1,1) masked | P.V(t,1) | softmax S(t+1,0)
-            m16_mask_init<1>(s, last_lim, G);
+            m16_mask_init<1>(s, last_lim, G, s.mq);
             m16_step<1, 2, true, true, SCALED>(s, qf, kf, vf, k_addr(s2, 1), v_addr(s1, 1), k_addr(s2, 1), v_addr(s2, 0), c_log2, M16NoDma());
             // u = 2t+3: P.V(t+1,0) | softmax S(t+1,1)
             m16_step<0, 0, true, true, SCALED>(s, qf, kf, vf, k_addr(s2, 1), v_addr(s2, 0), k_addr(s2, 1), v_addr(s2, 1), c_log2, M16NoDma());
@@ -498,17 +566,23 @@ __global__ __launch_bounds__(M16_THREADS, 1) void attn_hd128_m16_kernel(
         // the last prefetches of the chain are never consumed: keep the ring alive until they have landed
         asm volatile("" ::"v"(kf[0]), "v"(kf[1]), "v"(kf[2]), "v"(kf[3]), "v"(vf[0]), "v"(vf[1]), "v"(vf[2]), "v"(vf[3]));
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {       // absolute scale: ONE range test of the final row sums (2^-60 .. 2^90; inf / NaN too)
+        for (int n = 0; n < 4; ++n) {       // ONE range test of the final row sums (2^-64 .. 2^90 expected; inf / NaN fail too)
             float lt = s.l_run[n] + __shfl_xor(s.l_run[n], 16, 64);
             lt += __shfl_xor(lt, 32, 64);
-            s.bad |= !(lt >= 8.6736174e-19f && lt <= 1.2379400e27f);
+            s.bad |= !(lt >= 8.4703295e-22f && lt <= 1.2379400e27f);       // 2^-70, 2^90
+            s.m_run[n] = -s.mq[n][0];       // what the lse below is relative to
         }
-        exact_pass = __syncthreads_or(s.bad) != 0;      // workgroup-uniform: the exact loop has barriers
-        if (exact_pass && flagcnt && tid == 0) atomicAdd(flagcnt, 1u);      // debug hook: how many blocks were redone
-        if (dbg & 1) exact_pass = false;                // debug: keep the pipelined result even when flagged
+        const bool flagged = __syncthreads_or(s.bad) != 0;      // workgroup-uniform: the sweep and the exact loop have barriers
+        if (!flagged || (dbg & 1)) break;                       // (debug bit 0: keep the pipelined result even when flagged)
+        if (flagcnt && tid == 0) atomicAdd(flagcnt + (attempt ? 1 : 0), 1u);   // debug hook: [0] blocks repeated, [1] blocks sent to the exact loop
+        if (attempt) {                      // flagged with the true maxima as reference: inf / NaN scores
+            exact_pass = true;
+            break;
+        }
+    }   // attempts
     }
     // ------------------------------------------------------------------------------------------
-    // exact pass: plain one-slot loop, true maxima; short rows, and blocks whose pipelined pass flagged
+    // exact pass: plain one-slot loop, running maxima; short rows, and blocks whose scores are not finite
     // ------------------------------------------------------------------------------------------
     if (exact_pass) {
         reset();

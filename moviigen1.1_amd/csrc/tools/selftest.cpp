@@ -340,21 +340,38 @@ static void test_attn(int64_t Lq, int64_t Lk, int heads, int nsamp, bool timeit,
 }
 
 // A/B of the attention kernel variants on ONE set of operands, interleaved rounds (cdna guide 5.4 rule 24).
-// data 0: uniform [-2,2) q/k (logit sigma 1.3: every row near-uniform); data 1: "realistic" — logit sigma ~8 with an
-// attention-sink key (+16 on every row), the regime of trained checkpoints.  Reports TFLOP/s per
-// variant and round, the count of query blocks the exact pass had to redo, and sampled-row errors vs a double reference.
+// data 0: uniform [-2,2) q/k (logit sigma 1.3 natural units: every row near-uniform);
+// data 1..4: logit sigma 8 / 16 / 24 / 40 natural units (the regime of trained checkpoints and far beyond), an
+//   attention-sink key (key 0: +2 sigma on every row) and a per-head gain spread (head h: 0.6 .. 1.0 of the nominal sigma);
+// data 5: sigma 24 with the sink at key L/2 (+3 sigma) instead of key 0 — the row maximum is NOT in the first key tile.
+// Reports TFLOP/s per variant and round, the count of query blocks that were repeated with swept maxima / sent to the
+// exact loop, and sampled-row errors vs a double reference.
+static const char* attn_ab_data_name(int data) {
+    static const char* names[] = {"uniform", "sigma8+sink+gains", "sigma16+sink+gains", "sigma24+sink+gains", "sigma40+sink+gains",
+                                  "sigma24+late-sink+gains"};
+    return data >= 0 && data < 6 ? names[data] : "?";
+}
 static void attn_ab(int64_t L, int heads, int data, const std::vector<int>& variants, int rounds) {
     const int64_t ld = (int64_t)heads * 128;
     const int64_t npk = (int64_t)heads * ((L + 63) / 64) * 8192;
-    const float amp = data ? 2.83f * 1.7320508f : 2.0f;       // uniform[-a,a) has sigma a/sqrt(3)
+    static const float sigmas[] = {0.f, 8.f, 16.f, 24.f, 40.f, 24.f};
+    const float sigma = data >= 1 && data <= 5 ? sigmas[data] : 0.f;
+    const float amp = data ? sqrtf(3.f * sigma) : 2.0f;       // uniform[-a,a) has variance a^2/3: logit sigma = a^2/3
     auto q = randbf((size_t)L * ld, amp), k = randbf((size_t)L * ld, amp), v = randbf((size_t)L * ld);
     if (data) {
-        for (int64_t i = 0; i < L; ++i)
-            for (int h = 0; h < heads; ++h) q[(size_t)i * ld + h * 128] = f2bf(3.f);
-        for (int h = 0; h < heads; ++h) k[(size_t)0 * ld + h * 128] = f2bf(60.f);     // the sink: +3*60/sqrt(128) = +15.9
+        const int64_t sink = data == 5 ? L / 2 : 0;
+        const float sink_sigmas = data == 5 ? 3.f : 2.f;
+        for (int h = 0; h < heads; ++h) {
+            const float gain = heads > 1 ? 0.6f + 0.4f * h / (heads - 1) : 1.f;
+            for (int64_t i = 0; i < L; ++i) {
+                for (int d = 1; d < 128; ++d) q[(size_t)i * ld + h * 128 + d] = f2bf(gain * bf2f(q[(size_t)i * ld + h * 128 + d]));
+                q[(size_t)i * ld + h * 128] = f2bf(3.f);
+            }
+            k[(size_t)sink * ld + h * 128] = f2bf(sink_sigmas * sigma * gain * sqrtf(128.f) / 3.f);    // 3 * this / sqrt(128) = + n sigma
+        }
     }
     Dev<uint16_t> dq(q), dk(k), dv(v), dkp((size_t)npk), dvp((size_t)npk), dout((size_t)L * ld);
-    Dev<unsigned> cnt(1);
+    Dev<unsigned> cnt(2);
     const float scale = 1.f / sqrtf(128.f);
     std::vector<uint16_t> qs(q.size());          // variants >= 10: the pre-scaled entry on bf16(q * scale*log2e)
     for (size_t i = 0; i < q.size(); ++i) qs[i] = f2bf(bf2f(q[i]) * scale * 1.4426950408889634f);
@@ -363,7 +380,7 @@ static void attn_ab(int64_t L, int heads, int data, const std::vector<int>& vari
     if (rc) { printf("pack_kv failed %d\n", rc); ++n_fail; return; }
     mg_attn_w64_flag_counter(cnt.p);
     const double flop = 4.0 * L * L * 128 * heads;
-    printf("attn_ab L=%lld heads=%d data=%s\n", (long long)L, heads, data ? "realistic(sigma8+sink)" : "uniform");
+    printf("attn_ab L=%lld heads=%d data=%d (%s)\n", (long long)L, heads, data, attn_ab_data_name(data));
     // reference rows (double), sampled once
     const int nsamp = 12;
     std::vector<int64_t> sq(nsamp); std::vector<int> sh(nsamp);
@@ -405,7 +422,7 @@ static void attn_ab(int64_t L, int heads, int data, const std::vector<int>& vari
             };
             rc |= run();
             CK(hipDeviceSynchronize());
-            const unsigned flagged = cnt.host()[0];
+            const unsigned flagged = cnt.host()[0], to_exact = cnt.host()[1];
             float ms = time_ms([&] { run(); }, 3);
             auto got = dout.host();
             double err = rc ? 1e9 : 0;
@@ -414,8 +431,8 @@ static void attn_ab(int64_t L, int heads, int data, const std::vector<int>& vari
                     err = fmax(err, fabs(bf2f(got[(size_t)sq[it] * ld + sh[it] * 128 + d]) - ref[it][d]));
             const bool ok = err <= 2e-2 * fmax(ref_max, 1e-3);
             if (!ok) ++n_fail;
-            printf("  [%s] variant %d round %d: %.3f ms  %.1f TFLOP/s  flagged blocks %u of %lld  max_err %.3e (ref max %.3e)\n",
-                   ok ? "PASS" : "FAIL", var, r, ms, flop / (ms * 1e-3) / 1e12, flagged, (long long)((L + 255) / 256) * heads, err, ref_max);
+            printf("  [%s] variant %d round %d: %.3f ms  %.1f TFLOP/s  flagged blocks %u (exact loop %u) of %lld  max_err %.3e (ref max %.3e)\n",
+                   ok ? "PASS" : "FAIL", var, r, ms, flop / (ms * 1e-3) / 1e12, flagged, to_exact, (long long)((L + 255) / 256) * heads, err, ref_max);
             fflush(stdout);
         }
     mg_attn_w64_flag_counter(nullptr);

@@ -90,7 +90,7 @@ MG_DEV void cv_epilogue(const ConvArgs& a, const f32x16_t (&acc)[NB], int64_t m_
     }
 }
 
-// FAST = the opt-in split-bf16 mode (mg_vae_set_mode(1)): every fp32 operand is split once, when its tile is staged, into
+// FAST = the opt-in split-bf16 mode (mode = MG_VAE_BF16X3): every fp32 operand is split once, when its tile is staged, into
 // hi = bf16(x) and lo = bf16(x - hi) — 16 mantissa bits — and the product runs as W_hi.X_hi + W_hi.X_lo + W_lo.X_hi on
 // v_mfma_f32_32x32x16_bf16 with the same fp32 accumulators (the dropped lo.lo term is 2^-18 of a product): 6 MFMAs of 32
 // cycles per 32-channel chunk and cout block instead of 16 of 64.  LDS rows keep their 144 bytes: 32 hi (64 B) | 32 lo
@@ -323,10 +323,10 @@ __global__ __launch_bounds__(CV_THREADS) void vae_conv_kernel(const ConvArgs a) 
     cv_epilogue<NB, 1>(a, acc, m_in, m_out, n0, g);
 }
 
-static int g_vae_mode = 0;      // 0 = exact fp32 MFMA (the reference's arithmetic), 1 = split-bf16 x 3 (opt-in fast mode)
-extern "C" void mg_vae_set_mode(int mode) { g_vae_mode = mode == 1 ? 1 : 0; }
-
-static int launch_conv(const ConvArgs& a, hipStream_t st, bool allow_fast = true) {
+// mode: MG_VAE_EXACT = fp32 MFMA (the reference's arithmetic), MG_VAE_BF16X3 = split-bf16 x 3 (opt-in fast mode) — an
+// argument of every call (ABI 7): two decodes on two streams or threads cannot change each other's arithmetic
+static int launch_conv(const ConvArgs& a, hipStream_t st, int mode) {
+    if (mode != MG_VAE_EXACT && mode != MG_VAE_BF16X3) return MG_ERR_ARG;
     if ((int64_t)(a.T > a.tc ? a.T : a.tc) * a.H * a.W > 0x7fffffffLL) return MG_ERR_SHAPE;   // 32-bit voxel index in the gather
     if (a.kt * a.kh * a.kw > 1 && a.Cin > 1024) return MG_ERR_SHAPE;                           // padding taps index the zero page by channel
     const int64_t tiles_m = (a.M + CV_BM - 1) / CV_BM;
@@ -338,7 +338,7 @@ static int launch_conv(const ConvArgs& a, hipStream_t st, bool allow_fast = true
     else nb = 4;
     const int bn = 32 * nb;
     const dim3 grid((unsigned)tiles_m, (unsigned)((a.Cout + bn - 1) / bn), a.phases ? 4u : 1u), block(CV_THREADS);
-    if (g_vae_mode == 1 && allow_fast) {
+    if (mode == MG_VAE_BF16X3) {
         if (nb == 1) hipLaunchKernelGGL((vae_conv_kernel<1, true>), grid, block, 0, st, a);
         else if (nb == 3) hipLaunchKernelGGL((vae_conv_kernel<3, true>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((vae_conv_kernel<4, true>), grid, block, 0, st, a);
@@ -352,7 +352,7 @@ static int launch_conv(const ConvArgs& a, hipStream_t st, bool allow_fast = true
 
 extern "C" int mg_vae_conv_f32(const float* x, const float* cache, int tc, int T, int H, int W, int Cin,
                                const float* w, const float* bias, int Cout, int kt, int kh, int kw, int up2,
-                               const float* residual, float* out, void* stream) {
+                               const float* residual, float* out, int mode, void* stream) {
     if (!x || !w || !out) return MG_ERR_ARG;
     if (T <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 3) || Cout <= 0 || kt < 1 || kh < 1 || kw < 1 ||
         !(kh & 1) || !(kw & 1) || tc < 0 || tc > kt - 1 || (tc > 0 && !cache))
@@ -369,7 +369,7 @@ extern "C" int mg_vae_conv_f32(const float* x, const float* cache, int tc, int T
     a.up2 = up2 ? 1 : 0; a.residual = residual; a.out = out; a.ldo = Cout;
     a.Ho = up2 ? 2 * H : H; a.Wo = up2 ? 2 * W : W; a.M = (int64_t)T * a.Ho * a.Wo; a.out_scale = 1.f;
     a.phases = 0; a.w_phase_stride = 0;
-    return launch_conv(a, (hipStream_t)stream);
+    return launch_conv(a, (hipStream_t)stream, mode);
 }
 
 // w [Cout][1][3][3][Cin] -> wp [4 phases = 2 py + px][Cout][2][2][Cin]: the taps of a 3x3 kernel that fall on the same image
@@ -400,7 +400,7 @@ extern "C" int mg_vae_upconv_fold_weights_f32(const float* w, int Cout, int Cin,
 }
 
 extern "C" int mg_vae_upconv_phases_f32(const float* x, int T, int H, int W, int Cin, const float* wp, const float* bias,
-                                        int Cout, float* out, void* stream) {
+                                        int Cout, float* out, int mode, void* stream) {
     if (!x || !wp || !out) return MG_ERR_ARG;
     if (T <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 3) || Cout <= 0) return MG_ERR_SHAPE;
     if (((uintptr_t)x & 15) || ((uintptr_t)wp & 15) || ((uintptr_t)out & 15) || (bias && ((uintptr_t)bias & 15))) return MG_ERR_SHAPE;
@@ -410,7 +410,7 @@ extern "C" int mg_vae_upconv_phases_f32(const float* x, int T, int H, int W, int
     a.w = wp; a.ldw = (int64_t)4 * Cin; a.bias = bias; a.Cout = Cout; a.kt = 1; a.kh = 2; a.kw = 2; a.up2 = 0;
     a.residual = nullptr; a.out = out; a.ldo = Cout; a.Ho = H; a.Wo = W; a.M = (int64_t)T * H * W; a.out_scale = 1.f;
     a.phases = 1; a.w_phase_stride = (int64_t)Cout * 4 * Cin;
-    return launch_conv(a, (hipStream_t)stream);
+    return launch_conv(a, (hipStream_t)stream, mode);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -538,13 +538,13 @@ extern "C" int mg_vae_attn_f32(const float* qkv, float* out, int frames, int64_t
             a.w = base + C; a.ldw = 3 * C; a.bias = nullptr; a.Cout = (int)L; a.kt = a.kh = a.kw = 1; a.up2 = 0;
             a.residual = nullptr; a.out = S; a.ldo = Lp; a.Ho = 1; a.Wo = (int)nq; a.M = nq;
             a.out_scale = 1.f / sqrtf((float)C);
-            int rc = launch_conv(a, st, false);     // the attention block's two GEMMs stay exact in either mode
+            int rc = launch_conv(a, st, MG_VAE_EXACT);     // the attention block's two GEMMs are exact in either mode
             if (rc) return rc;
             hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)nq), dim3(256), 0, st, S, L, Lp);
             // out[nq][C] = P[nq][Lp] . vT[C][Lp]^T   (padding columns are zero on both sides)
             a.x = S; a.ldx = Lp; a.Cin = (int)Lp; a.w = vT; a.ldw = Lp; a.Cout = C; a.out = out + ((int64_t)f * L + q0) * C;
             a.ldo = C; a.out_scale = 1.f;
-            rc = launch_conv(a, st, false);
+            rc = launch_conv(a, st, MG_VAE_EXACT);
             if (rc) return rc;
         }
     }

@@ -39,10 +39,9 @@ SIGNATURES = {
     'mg_ew_bf16': [c_vp, c_vp, c_vp, c_i64, c_int, c_vp],
     'mg_t5_attn_bf16': [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_vp],
     'mg_vae_conv_f32': [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int,
-                        c_int, c_vp, c_vp, c_vp],
+                        c_int, c_vp, c_vp, c_int, c_vp],
     'mg_vae_upconv_fold_weights_f32': [c_vp, c_int, c_int, c_vp, c_vp],
-    'mg_vae_upconv_phases_f32': [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp],
-    'mg_vae_set_mode': [c_int],
+    'mg_vae_upconv_phases_f32': [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_int, c_vp],
     'mg_vae_rmsnorm_silu_f32': [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp],
     'mg_vae_attn_workspace_floats': [c_i64, c_int],
     'mg_vae_attn_f32': [c_vp, c_vp, c_int, c_i64, c_int, c_vp, c_vp],
@@ -69,7 +68,7 @@ SIGNATURES = {
     'mg_sp_copy_blocks_bf16': [c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_int, c_i64, c_int, c_vp],
     'mg_sp_unpack_o_bf16': [c_vp, c_i64, c_int, c_int, c_int, c_int, c_vp, c_i64, c_vp],
 }
-_RESTYPE = {'mg_version': ctypes.c_char_p, 'mg_vae_attn_workspace_floats': ctypes.c_int64, 'mg_attn_set_variant': None, 'mg_vae_set_mode': None,
+_RESTYPE = {'mg_version': ctypes.c_char_p, 'mg_vae_attn_workspace_floats': ctypes.c_int64, 'mg_attn_set_variant': None,
             'mg_gemm_set_variant': None, 'mg_attn_w64_profile': None,
             'mg_attn_w64_debug': None, 'mg_attn_w64_flag_counter': None, 'mg_gemm_debug_profile': None, 'mg_gemm5_debug_profile': None}
 DEFAULT_GEMM_VARIANT = 0   # must match g_gemm_variant in csrc/gemm_bf16.hip (0 = by shape and epilogue)

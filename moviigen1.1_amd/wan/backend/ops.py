@@ -196,14 +196,17 @@ def t5_attention(q, k, v, rel_emb, rel_bucket, out, lk, heads, head_dim):
 
 
 # ---- VAE (fp32, channels-last) -------------------------------------------------------------------
-def vae_conv(x, w, bias, out, kt, kh, kw, cache=None, up2=False, residual=None):
+VAE_EXACT, VAE_BF16X3 = 0, 1     # MG_VAE_EXACT / MG_VAE_BF16X3 (include/moviigen_hip.h): the arithmetic of one convolution call
+
+
+def vae_conv(x, w, bias, out, kt, kh, kw, cache=None, up2=False, residual=None, mode=VAE_EXACT):
     """x [T,H,W,Cin]; w [Cout,kt,kh,kw,Cin]; out [T,Ho,Wo,Cout]."""
     for n, t in (('x', x), ('w', w), ('bias', bias), ('out', out), ('cache', cache), ('residual', residual)):
         _chk(t, torch.float32, n)
     T, H, W, Cin = x.shape
     tc = 0 if cache is None else cache.shape[0]
     lib.call('mg_vae_conv_f32', _p(x), _p(cache), tc, T, H, W, Cin, _p(w), _p(bias), w.shape[0], kt, kh, kw,
-             int(up2), _p(residual), _p(out), _st())
+             int(up2), _p(residual), _p(out), int(mode), _st())
     return out
 
 
@@ -218,12 +221,12 @@ def vae_upconv_fold_weights(w):
     return wp
 
 
-def vae_upconv_phases(x, wp, bias, out):
+def vae_upconv_phases(x, wp, bias, out, mode=VAE_EXACT):
     """x [T,H,W,Cin]; wp from vae_upconv_fold_weights; out [T,2H,2W,Cout] = conv3x3(nearest-2x(x))."""
     for n, t in (('x', x), ('wp', wp), ('bias', bias), ('out', out)):
         _chk(t, torch.float32, n)
     T, H, W, Cin = x.shape
-    lib.call('mg_vae_upconv_phases_f32', _p(x), T, H, W, Cin, _p(wp), _p(bias), wp.shape[1], _p(out), _st())
+    lib.call('mg_vae_upconv_phases_f32', _p(x), T, H, W, Cin, _p(wp), _p(bias), wp.shape[1], _p(out), int(mode), _st())
     return out
 
 

@@ -4,8 +4,11 @@ served by the MI355X attention kernels instead of flash_attn's CUDA kernels.
 Same signature and dtype contract: q [B,Lq,N,C], k/v [B,Lk,N,C]; inputs that are not fp16/bf16 are
 cast to `dtype`; the result comes back in q's original dtype.  Supported subset = what the DiT
 uses: non-causal, no dropout, no window, N_q == N_k.  WanModel itself does not go through this
-wrapper (it calls the kernels on packed buffers); it exists so that code bound to
-`wan.modules.model.flash_attention` keeps working."""
+wrapper (it calls the kernels on packed buffers).  The reference imports it BY NAME into
+wan/modules/model.py (:10) and calls that module-level name (:146-151, :176); the same binding
+exists here (`wan.modules.model.flash_attention`) and a caller who re-binds it is honoured: WanModel's
+layer loop then calls the bound function with the reference's arguments for every self- and
+cross-attention instead of the fused kernels (tests/test_gpu_parity.py::test_operator_seam_flash_attention)."""
 import math
 
 import torch

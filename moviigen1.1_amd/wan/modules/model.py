@@ -31,8 +31,19 @@ import torch
 import torch.nn as nn
 
 from ..backend import ops
+from .attention import flash_attention      # operator seam (1): the reference binds it here by name (model.py:10)
 
 __all__ = ['WanModel']
+
+_ENGINE_FLASH_ATTENTION = flash_attention
+
+
+def _rebound_flash_attention():
+    """the function a caller bound as `wan.modules.model.flash_attention` (the reference calls that module-level
+    name at model.py:146-151 and :176, so assigning it replaces the attention of every block), or None while the name
+    still is the engine's own operator — then the fused kernels on packed operands run instead of the wrapper."""
+    fn = globals()['flash_attention']
+    return None if fn is _ENGINE_FLASH_ATTENTION else fn
 
 _BF16_SUFFIXES = ('.q.weight', '.k.weight', '.v.weight', '.o.weight', 'ffn.0.weight', 'ffn.2.weight',
                   'text_embedding.0.weight', 'text_embedding.2.weight', 'patch_embedding.weight')
@@ -426,15 +437,16 @@ class WanModel(nn.Module):
         self._ctx_cache[key] = (ctx, emb, [None] * self.num_layers)  # keep ctx alive so data_ptr stays unique
         return self._ctx_cache[key]
 
-    def _cross_kv(self, i, lw, emb):
-        """cross-attention K (RMS-normed) and V of block i for one prompt (reference model.py:168-170)."""
+    def _cross_kv(self, i, lw, emb, row_major=False):
+        """cross-attention K (RMS-normed) and V of block i for one prompt (reference model.py:168-170): packed tile
+        buffers for the head_dim 128 kernel, row-major [text_len, dim] otherwise (and for a rebound flash_attention)."""
         dev, d, hd = emb.device, self.dim, self.dim // self.num_heads
         Lc, bf = self.text_len, torch.bfloat16
         kv = torch.empty(Lc, 2 * d, dtype=bf, device=dev)
         ops.gemm(emb, lw['wkv_c'], lw['bkv_c'], ops.BIAS_BF16, kv)
         kc = torch.empty(Lc, d, dtype=bf, device=dev)
         ops.rmsnorm_rope(kv[:, :d], self.blocks[i].cross_attn.norm_k.weight, self.eps, hd, kc)
-        if hd == 128:
+        if hd == 128 and not row_major:
             n_pk = ops.packed_kv_numel(Lc, self.num_heads)
             kcp, vcp = torch.empty(n_pk, dtype=bf, device=dev), torch.empty(n_pk, dtype=bf, device=dev)
             ops.pack_kv(kc, kv[:, d:], self.num_heads, kcp, vcp)
@@ -463,8 +475,17 @@ class WanModel(nn.Module):
         d, hd, N = self.dim, self.dim // self.num_heads, self.num_heads
         qkv = ws['qkv']
         sa = blk.self_attn
-        ops.rmsnorm_rope(qkv[:, :d], sa.norm_q.weight, self.eps, hd, ws['q'], rope, grid, pos0, out_scale=self._q_scale())
+        fa = _rebound_flash_attention() if self.sp_size == 1 and not self.sp_force else None
+        ops.rmsnorm_rope(qkv[:, :d], sa.norm_q.weight, self.eps, hd, ws['q'], rope, grid, pos0,
+                         out_scale=self._q_scale() if fa is None else 1.0)
         ops.rmsnorm_rope(qkv[:, d:2 * d], sa.norm_k.weight, self.eps, hd, ws['k'], rope, grid, pos0)
+        if fa is not None:
+            # operator seam (1): the caller's function gets the reference's call (model.py:146-151): q, k roped
+            # [1, L, N, hd] (UNSCALED: softmax_scale is the callee's business), v, k_lens, window_size
+            y = fa(q=ws['q'].view(1, L, N, hd), k=ws['k'].view(1, L, N, hd), v=qkv[:, 2 * d:].reshape(1, L, N, hd),
+                   k_lens=torch.tensor([self._kv_valid]), window_size=self.window_size)
+            ws['a'].copy_(y.reshape(L, d))
+            return
         if self.sp_size == 1 and not self.sp_force:
             if hd == 128:
                 kv = self._kv_valid        # rows past the video's tokens are padding: never packed, never attended
@@ -593,13 +614,22 @@ class WanModel(nn.Module):
                 ops.gate_residual(x, y[0].to(torch.bfloat16).contiguous(), m[2])
             # cross attention (text keys/values cached per prompt)
             ca = blk.cross_attn
-            if ctx_layers[i] is None:          # first forward with this prompt
-                ctx_layers[i] = self._cross_kv(i, lw, ctx_emb)
-            kc, vc = ctx_layers[i]
+            fa = _rebound_flash_attention()
+            if ctx_layers[i] is None or (len(ctx_layers[i]) == 3) != (fa is not None):  # first forward with this prompt
+                ctx_layers[i] = self._cross_kv(i, lw, ctx_emb) if fa is None else \
+                    self._cross_kv(i, lw, ctx_emb, row_major=True) + ('row-major',)
+            kc, vc = ctx_layers[i][:2]
             ops.ln_modulate(x, blk.norm3.weight, blk.norm3.bias, False, eps, ws['h'])
             ops.gemm(ws['h'], lw['cross_attn.q'], ca.q.bias, ops.BIAS_BF16, ws['q'])
-            ops.rmsnorm_rope(ws['q'], ca.norm_q.weight, eps, d // self.num_heads, ws['k'], out_scale=self._q_scale())
-            if self.cross_attn_head_sharded and P > 1:
+            ops.rmsnorm_rope(ws['q'], ca.norm_q.weight, eps, d // self.num_heads, ws['k'],
+                             out_scale=self._q_scale() if fa is None else 1.0)
+            if fa is not None:
+                # operator seam (1), reference model.py:176: flash_attention(q, k, v, k_lens=context_lens) with
+                # context_lens = None for T2V
+                N, hd = self.num_heads, d // self.num_heads
+                y = fa(ws['k'].view(1, L, N, hd), kc.view(1, -1, N, hd), vc.reshape(1, -1, N, hd), k_lens=None)
+                ws['a'].copy_(y.reshape(L, d))
+            elif self.cross_attn_head_sharded and P > 1:
                 self._cross_attention_head_sharded(ws, kc, vc)
             else:
                 self._attention(ws['k'], kc, vc, ws['a'], self.text_len, self.num_heads)

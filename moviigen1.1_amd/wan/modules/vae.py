@@ -13,7 +13,6 @@ bias and the residual add folded in; RMS_norm+SiLU and the per-frame d=384 atten
 kernels as well.  The chunked decode with its 2-frame feature cache follows the reference
 protocol (vae.py:101-141,202-220,423-472,544-568) slot for slot.
 """
-import contextlib
 import logging
 import os
 
@@ -44,7 +43,8 @@ class WanVAE_:
         if mode not in ('exact', 'bf16x3'):
             raise ValueError(f"mode must be 'exact' (the reference's fp32 arithmetic) or 'bf16x3', got {mode!r}")
         self.upconv = upconv
-        self.mode = mode          # 'bf16x3': opt-in split-bf16 convolutions (~1e-5 relative per conv), see mg_vae_set_mode
+        self.mode = mode          # 'bf16x3': opt-in split-bf16 convolutions (~1e-5 relative per conv)
+        self._conv_mode = ops.VAE_BF16X3 if mode == 'bf16x3' else ops.VAE_EXACT    # passed with every conv call (ABI 7)
         self.z_dim = z_dim
         self.device = torch.device(device)
         self.P = {}
@@ -79,7 +79,8 @@ class WanVAE_:
         kt, kh, kw = w.shape[1:4]
         T, H, W, _ = x.shape
         out = self._new(T, 2 * H if up2 else H, 2 * W if up2 else W, w.shape[0])
-        return ops.vae_conv(x, w, self.P[name + '.bias'], out, kt, kh, kw, cache=cache, up2=up2, residual=residual)
+        return ops.vae_conv(x, w, self.P[name + '.bias'], out, kt, kh, kw, cache=cache, up2=up2, residual=residual,
+                            mode=self._conv_mode)
 
     def _cached_conv(self, name, x, cache, idx, residual=None):
         """the feat_cache protocol of every 3x3x3 conv (reference vae.py:205-217)."""
@@ -144,7 +145,7 @@ class WanVAE_:
         if wp is None:                                   # folded once per checkpoint
             wp = self.P[name + '.phases'] = ops.vae_upconv_fold_weights(self.P[name + '.weight'])
         T, H, W, _ = x.shape
-        return ops.vae_upconv_phases(x, wp, self.P[name + '.bias'], self._new(T, 2 * H, 2 * W, wp.shape[1]))
+        return ops.vae_upconv_phases(x, wp, self.P[name + '.bias'], self._new(T, 2 * H, 2 * W, wp.shape[1]), mode=self._conv_mode)
 
     # ---- the decoder as a list of stages (each owns a contiguous range of feat_cache slots) ---------
     def _stages(self):
@@ -203,21 +204,7 @@ class WanVAE_:
     @torch.no_grad()
     def decode(self, z, chunks=None):
         """z [16,T,h,w] -> [3, 1+4(T-1), 8h, 8w] fp32 clamped to [-1,1]."""
-        with self._mode_scope():
-            return self._decode(z, chunks)
-
-    @contextlib.contextmanager
-    def _mode_scope(self):
-        """the library's arithmetic switch is process-global: 'bf16x3' is set for the duration of one decode only."""
-        if self.mode != 'bf16x3':
-            yield
-            return
-        from ..backend import lib
-        lib.load().mg_vae_set_mode(1)
-        try:
-            yield
-        finally:
-            lib.load().mg_vae_set_mode(0)
+        return self._decode(z, chunks)
 
     def _decode(self, z, chunks=None):
         z = z.to(self.device, torch.float32).contiguous()
@@ -257,8 +244,7 @@ class WanVAE_:
         P, rank = dist.get_world_size(group), dist.get_rank(group)
         if P == 1:
             return self.decode(z)
-        with self._mode_scope():
-            return self._decode_pipelined(z, group, P, rank)
+        return self._decode_pipelined(z, group, P, rank)
 
     def _decode_pipelined(self, z, group, P, rank):
         import torch.distributed as dist

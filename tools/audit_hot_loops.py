@@ -50,8 +50,14 @@ def audit(src, frag, skip, n_mfma, max_other):
         # the steady-state loop body = the basic block(s) inside a loop (LLVM marks their label lines "Loop") holding
         # exactly the iteration's MFMA count; the fewest other instructions wins when a peeled copy exists
         parts = re.split(r'^(\.LBB\d+_\d+:.*)$', body.split('.Lfunc_end')[0], flags=re.M)
-        cands = [blk for lab, blk in zip(parts[1::2], parts[2::2])
-                 if 'Loop' in lab and len(re.findall(r'\bv_mfma_', blk)) == n_mfma]
+        def loop_body(lab, blk):
+            # a block's text runs on to the next label: cut it at its own back edge (what follows is the loop's exit path)
+            me = lab.split(':')[0]
+            lines = blk.splitlines()
+            back = [i for i, ln in enumerate(lines) if re.search(r'\bs_cbranch\w*\s+' + re.escape(me) + r'\b', ln)]
+            return '\n'.join(lines[:back[-1] + 1]) if back else blk
+        cands = [loop_body(lab, blk) for lab, blk in zip(parts[1::2], parts[2::2]) if 'Loop' in lab]
+        cands = [blk for blk in cands if len(re.findall(r'\bv_mfma_', blk)) == n_mfma]
         if not cands:
             problems.append(f'{name}: no loop block with {n_mfma} MFMAs')
             continue
