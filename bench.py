@@ -204,8 +204,20 @@ def main():
                     help='skip the VAE decode / T5 legs measured after the timed region (profiling passes)')
     ap.add_argument('--no-cfg-parallel', action='store_true',
                     help='N > 1: Ulysses over all N ranks (the reference layout) instead of cond/uncond halves x Ulysses N/2')
+    ap.add_argument('--dit-fsdp', action='store_true',
+                    help="N > 1: DiT block weights sharded over ALL N ranks and all-gathered one block ahead (the reference's "
+                         '--dit_fsdp, wan/text2video.py:107-108 -> shard_model); with the default layout on 8 GPUs this is BASELINE '
+                         'configs[3]: cfg2 x ulysses_sp4 x fsdp8')
+    ap.add_argument('--vae-parallel', action='store_true',
+                    help='N > 1: the VAE decode of the sec/video tail as the layer-pipelined decode over all ranks '
+                         '(WanVAE.decode_pipelined) instead of rank 0 alone as in the reference (text2video.py:260-261)')
+    ap.add_argument('--transport', default=None, choices=['torch', 'rccl_direct', 'peer_copy'],
+                    help='N > 1: transport of the Ulysses exchange — torch.distributed nccl (default), the C-ABI collectives on the '
+                         "library's own RCCL communicator, or one-sided peer copies on the copy engines")
     ap.add_argument('--layers', type=int, default=None, help='debug only: fewer layers (marks the line invalid)')
     args = ap.parse_args()
+    if args.transport is not None:        # read by wan.distributed at exchange-construction time; inherited by self-launched ranks
+        os.environ['MOVIIGEN_SP_TRANSPORT'] = '' if args.transport == 'torch' else args.transport
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # plain `python bench.py --gpus N`: become the launcher of N ranks (the driver's torchrun form skips this)
@@ -261,6 +273,9 @@ def main():
         else:
             from wan.distributed.xdit_context_parallel import enable_sequence_parallel
             enable_sequence_parallel(model)
+        if args.dit_fsdp:
+            from wan.distributed.fsdp import shard_model
+            shard_model(model, device_id=local)       # 1/N of every block's GEMM weights per rank, gathered one block ahead
     sp = model.sp_size
     g = torch.Generator(device=dev).manual_seed(42)
     latent = torch.randn(*lat_shape, dtype=torch.float32, device=dev, generator=g)
@@ -311,9 +326,12 @@ def main():
     for i in range(args.warmup):
         step(i)
     fence()
+    from wan.distributed.fsdp import BlockShards
     from wan.distributed.ulysses import HeadExchange
     if world > 1:
         HeadExchange.trace = []          # events around every collective / every wait of the compute stream on one
+        if args.dit_fsdp:
+            BlockShards.trace = []
     recording['on'] = True
     t0 = time.perf_counter()
     for i in range(args.warmup, total):
@@ -321,13 +339,19 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     recording['on'] = False
-    overlap = rank_devices = None
+    overlap = rank_devices = fsdp_trace = None
+    peer_used = False
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = tt.item()
         overlap = HeadExchange.overlap_summary()
         HeadExchange.trace = None
+        peer_used = any('xchg' in w_ and w_['xchg'].peer is not None for w_ in model._ws.values())
+        if args.dit_fsdp:
+            from wan.distributed.collectives import trace_summary
+            fsdp_trace = trace_summary(BlockShards.trace)
+            BlockShards.trace = None
         mine = {'rank': rank, 'device': f'cuda:{local}', 'name': torch.cuda.get_device_name(dev),
                 'uuid': str(getattr(torch.cuda.get_device_properties(dev), 'uuid', ''))}
         rank_devices = [None] * world
@@ -338,21 +362,33 @@ def main():
     # region: WanVAE.decode of a latent of this size on rank 0 (the reference decodes on rank 0 only) and, reported
     # separately, the two umT5-XXL prompt encodes.  Random-init weights of the shipped architectures.
     vae_s = t5_s = None
-    if rank == 0 and not args.no_video_tail:
+    vae_pipe = args.vae_parallel and world > 1
+    if (rank == 0 or vae_pipe) and not args.no_video_tail:
         import weights as Wt
         z = latent.clone()
         model._ws = {}                       # the DiT activations are not needed any more
         torch.cuda.empty_cache()
         vae = wan.modules.WanVAE(state_dict=Wt.make_vae_params(96, 1), device=dev)
         vae.decode([z[:, :2, :16, :16].contiguous()])        # warm-up launch of every kernel (tiny latent)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        video = vae.decode([z])[0]
-        torch.cuda.synchronize()
+        if vae_pipe:
+            # --vae-parallel: the layer-pipelined decode over all ranks (every rank passes the same latent: the scheduler
+            # state is replicated); timed between two barriers, video on rank 0
+            vae.decode_pipelined([z[:, :2, :16, :16].contiguous()])
+            fence()
+            t1 = time.perf_counter()
+            video = vae.decode_pipelined([z])[0]
+            fence()
+        else:
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            video = vae.decode([z])[0]
+            torch.cuda.synchronize()
         vae_s = time.perf_counter() - t1
-        assert video.shape == (3, frames, Hd, Wd) and torch.isfinite(video).all().item()
+        if rank == 0:
+            assert video.shape == (3, frames, Hd, Wd) and torch.isfinite(video).all().item()
         del video, vae
         torch.cuda.empty_cache()
+    if rank == 0 and not args.no_video_tail:
         if not args.layers and args.workload != 'tiny':
             from wan.modules.t5 import umt5_xxl
             enc = umt5_xxl(device=dev)
@@ -396,7 +432,8 @@ def main():
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_step, 'higher_is_better': True,
             'scaling': 'strong', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
             'config': {'workload': desc, 'latent': list(lat_shape), 'tokens': L, 'layers': cfg['num_layers'],
-                       'parallelism': ('single' if world == 1 else f'cfg2 x ulysses_sp{sp}' if cfgp is not None else f'ulysses_sp{sp}'), 'solver': 'unipc',
+                       'parallelism': ('single' if world == 1 else f'cfg2 x ulysses_sp{sp}' if cfgp is not None else f'ulysses_sp{sp}')
+                                      + (f' x fsdp{world}' if args.dit_fsdp and world > 1 else ''), 'solver': 'unipc',
                        'guide_scale': 5.0, 'weights': 'random N(0,0.02) bf16, seed 0'},
             'sec_per_video': (ms_step * 50 / 1e3 + vae_s) if vae_s is not None else None,
             'sec_per_video_parts': {'denoise_50_steps_s': ms_step * 50 / 1e3, 'vae_decode_s': vae_s,
@@ -434,9 +471,23 @@ def main():
             gloo = os.environ.get('MOVIIGEN_BENCH_BACKEND') == 'gloo'
             line['rccl_ranks'] = 0 if gloo else world
             line['rank_devices'] = rank_devices
-            line['transport'] = ('gloo through host memory (test plumbing)' if gloo else
-                                 "C-ABI collectives on the library's RCCL communicator (mg_sp_all_to_all: grouped ncclSend/ncclRecv)"
-                                 if rccl_direct.enabled() else 'torch.distributed backend nccl (= RCCL): all_to_all_single on a comm stream')
+            # what the exchange objects REALLY use (a peer-copy request falls back to the collective when the IPC mapping fails)
+            line['transport'] = {
+                'requested': args.transport or os.environ.get('MOVIIGEN_SP_TRANSPORT') or 'torch',
+                'used': ('gloo through host memory (test plumbing)' if gloo else
+                         'one-sided peer copies (hipMemcpyAsync D2D into IPC-mapped receive buffers) between two flag all-reduces' if peer_used else
+                         "C-ABI collectives on the library's RCCL communicator (mg_sp_all_to_all: grouped ncclSend/ncclRecv)"
+                         if rccl_direct.enabled() else 'torch.distributed backend nccl (= RCCL): all_to_all_single on a comm stream')}
+            if fsdp_trace is not None:
+                per = 1.0 / args.steps
+                shard_b = sum(sh.numel() for sh in model._shards.shards) * 2
+                line['fsdp'] = {'ranks': world, 'gather_ms_per_step': fsdp_trace['comm_ms'] * per, 'exposed_ms_per_step': fsdp_trace['exposed_ms'] * per,
+                                'hidden_frac': fsdp_trace['hidden_frac'], 'gathers_per_step': fsdp_trace['collectives'] * per,
+                                'resident_weight_bytes_per_rank': shard_b, 'gathered_bytes_per_block': shard_b * world // cfg['num_layers'],
+                                'how': 'rank 0: timing events around every block all-gather on its comm stream (gather) and around every '
+                                       'wait of the compute stream for a gathered block (exposed); hidden = 1 - exposed / gather'}
+            if vae_s is not None:
+                line['vae_decode_layout'] = f'layer pipeline over {world} ranks (WanVAE.decode_pipelined)' if vae_pipe else 'rank 0 alone (reference text2video.py:260-261)'
             if overlap and overlap['collectives']:
                 per = 1.0 / args.steps
                 line['overlap'] = {'exchange_ms_per_step': overlap['exchange_ms'] * per, 'exposed_ms_per_step': overlap['exposed_ms'] * per,

@@ -1,0 +1,63 @@
+"""TEST TRANSPORT — not a product path.  The multi-process tests of this repository run N ranks on ONE GPU (the only
+kind of box the build has) with the `gloo` backend, and gloo cannot move device tensors: every collective below stages
+them through host memory, synchronously.  `collectives.py` enters this module on exactly one condition —
+`staged(tensor, group)`: the group's backend is gloo AND the tensor lives on a device — so under `nccl` (RCCL; every
+real multi-GPU run) none of this code is reachable.  Nothing here does arithmetic."""
+import torch
+import torch.distributed as dist
+
+
+def staged(t, group):
+    return t.is_cuda and dist.get_backend(group) == 'gloo'
+
+
+def all_to_all(recv, send, group):
+    s, r = send.cpu(), torch.empty(recv.shape, dtype=recv.dtype)
+    dist.all_to_all_single(r, s, group=group)
+    recv.copy_(r)
+
+
+def all_gather(out, x, group):
+    P = dist.get_world_size(group)
+    parts = [torch.empty(x.shape, dtype=x.dtype) for _ in range(P)]
+    dist.all_gather(parts, x.cpu().contiguous(), group=group)
+    out.copy_(torch.cat([p.reshape(-1) for p in parts]).view(out.shape))
+
+
+def broadcast(t, src, group):
+    h = t.cpu()
+    dist.broadcast(h, src=src, group=group)
+    t.copy_(h)
+
+
+def send(x, dst, group):
+    dist.send(x.detach().cpu().contiguous(), dst, group=group)
+
+
+def recv(x, src, group):
+    h = torch.empty(x.shape, dtype=x.dtype)
+    dist.recv(h, src, group=group)
+    x.copy_(h)
+    return x
+
+
+class RingHop:
+    """send_bufs -> nxt, recv_bufs <- prv through host copies; wait() lands them in the device buffers."""
+
+    def __init__(self, send_bufs, recv_bufs, nxt, prv, group):
+        self.host_r = [torch.empty(b.shape, dtype=b.dtype) for b in recv_bufs]
+        self.recv_bufs = recv_bufs
+        ops = [dist.P2POp(dist.isend, b.cpu(), nxt, group) for b in send_bufs] + \
+              [dist.P2POp(dist.irecv, t, prv, group) for t in self.host_r]
+        self.works = dist.batch_isend_irecv(ops)
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        for h, d in zip(self.host_r, self.recv_bufs):
+            d.copy_(h)
+
+
+def rendezvous(group):
+    torch.cuda.current_stream().synchronize()
+    dist.barrier(group=group)

@@ -13,6 +13,7 @@ row count per launch — and bit-identical results (each forward is the same com
 import torch
 import torch.distributed as dist
 
+from . import collectives
 from .xdit_context_parallel import enable_sequence_parallel
 
 
@@ -23,12 +24,7 @@ class CfgParallel:
     def exchange(self, mine):
         """mine: this half's prediction (cond on branch 0, uncond on branch 1) -> (cond, uncond)."""
         both = torch.empty(2, *mine.shape, dtype=mine.dtype, device=mine.device)
-        if dist.get_backend(self.pair_group) == 'gloo':   # tests: no _allgather_base, device tensors via the host
-            parts = [torch.empty(mine.shape, dtype=mine.dtype) for _ in range(2)]
-            dist.all_gather(parts, mine.cpu().contiguous(), group=self.pair_group)
-            both.copy_(torch.stack(parts))
-        else:
-            dist.all_gather_into_tensor(both, mine.contiguous(), group=self.pair_group)
+        collectives.all_gather(both, mine.contiguous(), self.pair_group)
         return both[0], both[1]
 
 

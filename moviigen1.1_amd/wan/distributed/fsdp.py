@@ -21,6 +21,8 @@ Works on CPU tensors with gloo as well (no streams) — that is how the CPU test
 import torch
 import torch.distributed as dist
 
+from . import collectives
+
 ORDER = ('self_attn.q', 'self_attn.k', 'self_attn.v', 'self_attn.o', 'cross_attn.q', 'cross_attn.k', 'cross_attn.v',
          'cross_attn.o', 'ffn.0', 'ffn.2')
 
@@ -33,6 +35,18 @@ def _get(block, dotted):
 
 
 class BlockShards:
+    # Measurement hook (bench.py --dit-fsdp), same form as HeadExchange.trace: while `trace` is a list every gather is
+    # bracketed by timing events on the comm stream ('comm') and every wait of the compute stream for a gathered block by
+    # timing events on the compute stream ('wait'); collectives.trace_summary() turns them into gather / exposed time.
+    trace = None
+
+    @classmethod
+    def _mark(cls, kind, stream):
+        if cls.trace is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(stream)
+            cls.trace.append((kind, ev))
+
     def __init__(self, model, group=None, sync_module_states=True):
         if not dist.is_initialized():
             raise RuntimeError('torch.distributed is not initialised (launch with torchrun, one process per GPU)')
@@ -41,7 +55,6 @@ class BlockShards:
         self.group = group if group is not None else dist.new_group(list(range(dist.get_world_size())))
         self.P = dist.get_world_size(self.group)
         self.rank = dist.get_rank(self.group)
-        self.staged = dist.get_backend(self.group) == 'gloo'
         self.shapes, self.offsets, self.shards = [], [], []
         dev = model.patch_embedding.weight.device
         self.dev = dev
@@ -80,26 +93,13 @@ class BlockShards:
         model._invalidate()
 
     def _bcast(self, flat):
-        if self.staged and flat.is_cuda:
-            h = flat.cpu()
-            dist.broadcast(h, src=dist.get_global_rank(self.group, 0), group=self.group)
-            flat.copy_(h)
-        else:
-            dist.broadcast(flat, src=dist.get_global_rank(self.group, 0), group=self.group)
+        collectives.broadcast(flat, dist.get_global_rank(self.group, 0), self.group)
 
     def _gather(self, i, slot):
         shard = self.shards[i]
         out = self.bufs[slot][:shard.numel() * self.P]
-        from . import rccl_direct
-        if shard.is_cuda and not self.staged and rccl_direct.enabled():
-            # mg_shard_all_gather, enqueued on the CURRENT stream: _issue() calls this under `with stream(self.comm)`
-            rccl_direct.comm_for(self.group).shard_all_gather(out, shard)
-        elif self.staged and shard.is_cuda:
-            parts = [torch.empty(shard.shape, dtype=shard.dtype) for _ in range(self.P)]
-            dist.all_gather(parts, shard.cpu(), group=self.group)
-            out.copy_(torch.cat(parts))
-        else:
-            dist.all_gather_into_tensor(out, shard, group=self.group)
+        # enqueued on the CURRENT stream: _issue() calls this under `with stream(self.comm)`
+        collectives.all_gather(out, shard, self.group, shard=True)
         self.in_buf[slot] = i
 
     def _issue(self, i):
@@ -109,7 +109,9 @@ class BlockShards:
         if self.cuda:
             with torch.cuda.stream(self.comm):
                 self.comm.wait_event(self.free[slot])     # compute finished with the previous tenant
+                self._mark('comm', self.comm)
                 self._gather(i, slot)
+                self._mark('comm', self.comm)
                 self.ready[slot].record(self.comm)
         else:
             self._gather(i, slot)
@@ -119,7 +121,10 @@ class BlockShards:
         slot = i % 2
         self._issue(i)
         if self.cuda:
-            torch.cuda.current_stream().wait_event(self.ready[slot])
+            cur = torch.cuda.current_stream()
+            self._mark('wait', cur)
+            cur.wait_event(self.ready[slot])
+            self._mark('wait', cur)
         n_blocks = len(self.shards)
         if prefetch and n_blocks > 1:
             nxt = (i + 1) % n_blocks

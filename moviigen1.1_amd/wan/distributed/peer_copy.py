@@ -23,9 +23,32 @@ import os
 import torch
 import torch.distributed as dist
 
+from . import collectives
+
 
 def enabled():
     return os.environ.get('MOVIIGEN_SP_TRANSPORT', '') == 'peer_copy'
+
+
+def open_windows(group, buffers):
+    """PeerWindows over `buffers`, or None — with a warning, the exchange then stays on the collective transport — when the
+    mapping cannot be set up on EVERY rank of the group (IPC export refused, e.g. under expandable_segments; a peer's
+    device not visible to this process: the mapped tensor lives on the SENDER's device index, so all GPUs of the group
+    must be visible to every rank — per-rank HIP_VISIBLE_DEVICES masks are not supported by this transport)."""
+    import logging
+    try:
+        win = PeerWindows(group, buffers)
+        ok = 1
+    except Exception as e:      # noqa: BLE001 — any failure to export / map means: do not use this transport
+        logging.warning(f'MOVIIGEN_SP_TRANSPORT=peer_copy: mapping the peers\' receive buffers failed ({type(e).__name__}: {e}); '
+                        'falling back to the all-to-all collective')
+        win, ok = None, 0
+    flag = torch.tensor([ok], dtype=torch.int32, device=buffers[0].device)
+    g = group if group is not None else dist.group.WORLD
+    if dist.get_backend(g) == 'gloo':
+        flag = flag.cpu()
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=g)           # all ranks or none
+    return win if int(flag.item()) == 1 else None
 
 
 class PeerWindows:
@@ -35,12 +58,17 @@ class PeerWindows:
         from torch.multiprocessing.reductions import reduce_tensor
         self.group = group if group is not None else dist.group.WORLD
         self.P, self.rank = dist.get_world_size(self.group), dist.get_rank(self.group)
-        self.gloo = dist.get_backend(self.group) == 'gloo'
         self.local = list(buffers)
         dev = self.local[0].device
-        mine = [reduce_tensor(b) for b in self.local]          # (rebuild_fn, args): picklable IPC description
+        try:
+            mine = [reduce_tensor(b) for b in self.local]      # (rebuild_fn, args): picklable IPC description
+        except Exception as e:      # noqa: BLE001 — export refused here: tell the peers instead of leaving them in the gather
+            mine = f'{type(e).__name__}: {e}'
         everyone = [None] * self.P
         dist.all_gather_object(everyone, mine, group=self.group)
+        failed = [f'rank {p}: {m}' for p, m in enumerate(everyone) if isinstance(m, str)]
+        if failed:
+            raise RuntimeError('IPC export of the receive buffers failed on ' + '; '.join(failed))
         self.views = []                                          # views[i][p] = buffer i of rank p, mapped here
         for i, b in enumerate(self.local):
             row = []
@@ -56,11 +84,7 @@ class PeerWindows:
         self._keep = everyone
 
     def _rendezvous(self):
-        if self.gloo:           # test plumbing on a shared GPU: host-synchronous
-            torch.cuda.current_stream().synchronize()
-            dist.barrier(group=self.group)
-        else:
-            dist.all_reduce(self.flag, group=self.group)        # enqueued on the current (communication) stream
+        collectives.rendezvous(self.flag, self.group)           # 4-byte all-reduce enqueued on the current (communication) stream
 
     def all_to_all(self, i, send):
         """buffer i of every rank <- the P chunks of `send` ([P, ...], chunk p goes to rank p), all_to_all_single layout:

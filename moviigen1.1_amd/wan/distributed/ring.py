@@ -14,6 +14,7 @@ import torch
 import torch.distributed as dist
 
 from ..backend import ops
+from . import collectives
 
 
 def enable_ring_attention(model, group=None):
@@ -28,7 +29,9 @@ def enable_ring_attention(model, group=None):
     model.ring = True
     model.uly_group, model.uly_size, model.ring_group, model.ring_size = None, None, None, None
     model._ws = {}
-    return model
+    from .xdit_context_parallel import tag_attention_modules
+    tag_attention_modules(model)        # the stand-alone self-attention operator then refuses the ring layout instead of
+    return model                        # silently running Ulysses over WORLD
 
 
 def enable_hybrid_sp(model, ulysses_size, ring_size, group=None):
@@ -59,22 +62,6 @@ def enable_hybrid_sp(model, ulysses_size, ring_size, group=None):
     return model
 
 
-def _exchange(send_bufs, recv_bufs, group, P, rank):
-    """post the hop: send_bufs -> rank+1, recv_bufs <- rank-1; returns the requests to wait on."""
-    nxt = dist.get_global_rank(group, (rank + 1) % P) if group is not dist.group.WORLD else (rank + 1) % P
-    prv = dist.get_global_rank(group, (rank - 1) % P) if group is not dist.group.WORLD else (rank - 1) % P
-    if dist.get_backend(group) == 'gloo':      # tests: device tensors are staged through the host
-        host_s = [b.cpu() for b in send_bufs]
-        host_r = [torch.empty(b.shape, dtype=b.dtype) for b in recv_bufs]
-        reqs = [dist.P2POp(dist.isend, t, nxt, group) for t in host_s] + \
-               [dist.P2POp(dist.irecv, t, prv, group) for t in host_r]
-        works = dist.batch_isend_irecv(reqs)
-        return works, (host_r, recv_bufs)
-    reqs = [dist.P2POp(dist.isend, t, nxt, group) for t in send_bufs] + \
-           [dist.P2POp(dist.irecv, t, prv, group) for t in recv_bufs]
-    return dist.batch_isend_irecv(reqs), None
-
-
 def ring_attention(q, k, v, out, ws, group, P, rank, heads, scale, prescaled=False):
     """q, k, v [Lloc, heads*128] bf16 (row strides free), out [Lloc, heads*128] bf16; prescaled: q already carries
     scale*log2(e) (ops.rmsnorm_rope out_scale).
@@ -85,16 +72,11 @@ def ring_attention(q, k, v, out, ws, group, P, rank, heads, scale, prescaled=Fal
     for j in range(P):
         pending = None
         if j + 1 < P:
-            pending = _exchange(list(cur), list(nxt), group, P, rank)
+            pending = collectives.ring_hop(list(cur), list(nxt), group, P, rank)     # send to rank+1, receive from rank-1
         ops.attention_hd128_lse(q, cur[0], cur[1], ws['part'], ws['lse'], Lloc, heads, scale, prescaled=prescaled)
         ops.attention_merge(ws['acc'], ws['lse_acc'], ws['part'], ws['lse'], heads, first=(j == 0),
                             out=out if j == P - 1 else None)
         if pending is not None:
-            works, staged = pending
-            for w in works:
-                w.wait()
-            if staged is not None:
-                for h, d in zip(*staged):
-                    d.copy_(h)
+            pending.wait()
             cur, nxt = nxt, cur
     return out

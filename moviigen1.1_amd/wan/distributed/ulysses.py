@@ -26,28 +26,18 @@ the layer becomes a software pipeline over them —
 
 Transports of the exchange: torch.distributed backend "nccl" (= RCCL; default), the library's own RCCL communicator
 (MOVIIGEN_SP_TRANSPORT=rccl_direct: C-ABI mg_sp_all_to_all) or one-sided peer copies on the copy engines
-(MOVIIGEN_SP_TRANSPORT=peer_copy: peer_copy.py).  `gloo` with CUDA tensors (the multi-process tests on a 1-GPU box) is
-staged through host memory — test plumbing only; production is device to device.  `seq_to_head` / `head_to_seq` keep the
-one-tensor call shape of the reference libraries (used by the training-side SP forward and tests).
+(MOVIIGEN_SP_TRANSPORT=peer_copy: peer_copy.py) — the calls themselves live in collectives.py (device to device; the
+host-staged gloo transport of the one-GPU multi-process tests is behind its single guard there).  `seq_to_head` /
+`head_to_seq` keep the one-tensor call shape of the reference libraries (used by the training-side SP forward and tests).
 """
 import os
 
 import torch
-import torch.distributed as dist
 
 from ..backend import ops
-from . import peer_copy, rccl_direct
+from . import collectives, peer_copy
 
-
-def _a2a(recv, send, group):
-    if send.is_cuda and rccl_direct.enabled() and dist.get_backend(group) != 'gloo':
-        rccl_direct.comm_for(group).all_to_all(recv, send)      # C-ABI collective on the library's own communicator
-    elif send.is_cuda and dist.get_backend(group) == 'gloo':
-        s, r = send.cpu(), torch.empty(recv.shape, dtype=recv.dtype)
-        dist.all_to_all_single(r, s, group=group)
-        recv.copy_(r)
-    else:
-        dist.all_to_all_single(recv, send, group=group)
+_a2a = collectives.all_to_all
 
 
 def split_heads(n_loc, max_groups):
@@ -84,14 +74,8 @@ class HeadExchange:
     @classmethod
     def overlap_summary(cls):
         """-> dict(exchange_ms, exposed_ms, hidden_frac) over everything traced so far (call after a device sync)."""
-        tr = cls.trace or []
-        tot = {'comm': 0.0, 'wait': 0.0}
-        for i in range(0, len(tr) - 1, 2):
-            (k0, a), (k1, b) = tr[i], tr[i + 1]
-            assert k0 == k1
-            tot[k0] += a.elapsed_time(b)
-        hidden = 1.0 - tot['wait'] / tot['comm'] if tot['comm'] > 0 else None
-        return {'exchange_ms': tot['comm'], 'exposed_ms': tot['wait'], 'hidden_frac': hidden, 'collectives': len(tr) // 4}
+        s = collectives.trace_summary(cls.trace or [])
+        return {'exchange_ms': s['comm_ms'], 'exposed_ms': s['exposed_ms'], 'hidden_frac': s['hidden_frac'], 'collectives': s['collectives']}
 
     def __init__(self, group, P, heads, head_dim, Lloc, device, max_groups=None):
         if heads % P:
@@ -115,7 +99,7 @@ class HeadExchange:
         # one-sided device copies on the comm stream (copy engines, no CUs) between two 4-byte rendezvous
         self.peer = None
         if peer_copy.enabled() and self.recv[0].is_cuda and group is not None:
-            self.peer = peer_copy.PeerWindows(group, self.recv + self.orecv)
+            self.peer = peer_copy.open_windows(group, self.recv + self.orecv)      # None (logged) when IPC mapping is unavailable
         self.comm = torch.cuda.Stream(device=device)
         ev = lambda: [torch.cuda.Event() for _ in self.groups]  # noqa: E731
         self.ev_pack, self.ev_recv, self.ev_attn, self.ev_o = ev(), ev(), ev(), ev()
@@ -193,33 +177,6 @@ def head_to_seq(x, out, group, P, heads, head_dim):
 def all_gather_seq(x, group, P):
     """x [Lloc, C] -> [P*Lloc, C] (rank-order concatenation; get_sp_group().all_gather(dim=1))."""
     out = torch.empty(P * x.shape[0], x.shape[1], dtype=x.dtype, device=x.device)
-    if x.is_cuda and rccl_direct.enabled() and dist.get_backend(group) != 'gloo':
-        rccl_direct.comm_for(group).all_gather(out, x.contiguous())
-    elif x.is_cuda and dist.get_backend(group) == 'gloo':
-        parts = [torch.empty(x.shape, dtype=x.dtype) for _ in range(P)]
-        dist.all_gather(parts, x.cpu().contiguous(), group=group)
-        out.copy_(torch.cat(parts, 0))
-    else:
-        dist.all_gather_into_tensor(out, x.contiguous(), group=group)
+    collectives.all_gather(out, x.contiguous(), group)
     return out
 
-
-def p2p_send(x, dst, group=None):
-    """activation of a pipeline cut -> rank dst: a 4-int64 shape header, then the fp32 payload."""
-    hdr = torch.tensor(list(x.shape) + [0] * (4 - x.dim()), dtype=torch.int64)
-    if dist.get_backend(group) == 'gloo':            # tests: device tensors are staged through the host
-        dist.send(hdr, dst, group=group)
-        dist.send(x.detach().cpu().contiguous(), dst, group=group)
-    else:
-        dist.send(hdr.to(x.device), dst, group=group)
-        dist.send(x.contiguous(), dst, group=group)
-
-
-def p2p_recv(src, device, group=None):
-    gloo = dist.get_backend(group) == 'gloo'
-    hdr = torch.empty(4, dtype=torch.int64, device='cpu' if gloo else device)
-    dist.recv(hdr, src, group=group)
-    shape = [int(v) for v in hdr.tolist() if v > 0]
-    x = torch.empty(*shape, dtype=torch.float32, device='cpu' if gloo else device)
-    dist.recv(x, src, group=group)
-    return x.to(device)

@@ -211,15 +211,12 @@ class WanVAE_:
         C, T, H, W = z.shape
         x = ops.vae_latent_in(z, self.mean, self.inv_std, self._new(T, H, W, C))
         x = self._conv('conv2', x)
-        if chunks is None:
-            # The reference decodes ONE latent frame per decoder call (vae.py:555-566) to bound its peak memory (2.45 GB
-            # per activation at 832x1920); the cache protocol makes any chunking of frames 1.. give the same values
-            # (tests: chunked == unchunked).  With 288 GB of HBM the engine decodes 4 latent frames
-            # per call: the low-resolution stages then launch enough tiles to fill 256 CUs (9.77 vs 10.16 s at
-            # 1920x832, peak 45 GB).  MOVIIGEN_VAE_CHUNK=1 restores the reference's chunking.
-            n = max(1, int(os.environ.get('MOVIIGEN_VAE_CHUNK', '4')))
-            chunks = [1] + [n] * ((T - 1) // n) + ([(T - 1) % n] if (T - 1) % n else [])
-        assert sum(chunks) == T and chunks[0] == 1
+        # The reference decodes ONE latent frame per decoder call (vae.py:555-566) to bound its peak memory (2.45 GB per
+        # activation at 832x1920); the cache protocol makes any chunking of frames 1.. give the same values (SURVEY
+        # Appendix A; tests: chunked == unchunked).  With 288 GB of HBM the engine decodes 4 latent frames per call: the
+        # low-resolution stages then launch enough tiles to fill 256 CUs (9.77 vs 10.16 s at 1920x832, peak 45 GB).
+        # MOVIIGEN_VAE_CHUNK=1 restores the reference's chunking.
+        chunks = self._chunks(T, chunks)
         cache = [None] * (self.n_slots + 8)
         video = self._new(3, 1 + 4 * (T - 1), 8 * H, 8 * W)
         t0, f0 = 0, 0
@@ -231,28 +228,71 @@ class WanVAE_:
         assert f0 == video.shape[1]
         return video
 
+    def _chunks(self, T, chunks=None):
+        """the latent-frame chunking of a decode: frame 0 alone (the 'Rep' protocol of the temporal up-samplers needs it),
+        then MOVIIGEN_VAE_CHUNK (default 4) frames per decoder call — see _decode."""
+        if chunks is None:
+            n = max(1, int(os.environ.get('MOVIIGEN_VAE_CHUNK', '4')))
+            chunks = [1] + [n] * ((T - 1) // n) + ([(T - 1) % n] if (T - 1) % n else [])
+        assert sum(chunks) == T and chunks[0] == 1
+        return chunks
+
+    def stage_out_shape(self, last, n, first_chunk, H, W):
+        """[frames, H', W', C] of the activation that leaves stage `last - 1` for a chunk of n latent frames at latent size
+        H x W — what crosses a pipeline cut (the receiver allocates from this; no shape header travels)."""
+        f, C = n, self.z_dim
+        for kind, pre, _ in self._stages()[:last]:
+            if kind == 'conv1':
+                C = self.P[pre + '.weight'].shape[0]
+            elif kind == 'res':
+                C = self.P[pre + 'residual.6.weight'].shape[0]
+            elif kind == 'up':
+                if (pre + 'time_conv.weight') in self.P and not first_chunk:
+                    f *= 2                              # the first chunk skips time_conv ('Rep', reference vae.py:106-108)
+                H, W, C = 2 * H, 2 * W, self.P[pre + 'resample.1.weight'].shape[0]
+            elif kind == 'head':
+                C = self.P['decoder.head.2.weight'].shape[0]
+        return (f, H, W, C)
+
+    def stage_weights(self, h, w, stage_ms=None):
+        """what the pipelined decode balances: measured milliseconds per stage and steady-state chunk when given
+        (tools/bench_vae.py --stages prints them for a size), else MACs x the measured cost per MAC of the stage's kernel
+        class (REL_MS_PER_MAC: the 96-channel stage runs at a different efficiency than the 384-channel ones, the Cout = 3
+        head burns 29 of 32 MFMA columns, the attention block is three small launches per 2048 query rows)."""
+        if stage_ms is not None:
+            assert len(stage_ms) == len(self._stages())
+            return list(stage_ms)
+        out, base = [], self.P['decoder.head.0.gamma'].numel()         # the decoder's `dim` (96): its narrowest stage
+        for (kind, pre, _), c in zip(self._stages(), self.stage_costs(h, w)):
+            k = kind
+            if kind in ('conv1', 'res'):
+                cout = self.P[pre + ('.weight' if kind == 'conv1' else 'residual.6.weight')].shape[0]
+                k = 'narrow' if cout == base else 'wide'
+            out.append(c * REL_MS_PER_MAC[k])
+        return out
+
     @torch.no_grad()
-    def decode_pipelined(self, z, group=None):
-        """Multi-GPU decode: the stage list is cut into world_size contiguous
-        segments of about equal cost; segment s runs on rank P-1-s, so rank 0 owns the head and
-        assembles the video.  Chunks (latent frames) flow through the ranks as a pipeline — the causal
-        feat_cache of a conv stays on the rank that owns the conv, only the activation of the cut
-        crosses ranks (one send/recv per chunk and cut).  Exactly the single-GPU arithmetic.
-        Every rank passes the same latent; returns the video on rank 0, None elsewhere."""
+    def decode_pipelined(self, z, group=None, chunks=None, stage_ms=None):
+        """Multi-GPU decode: the stage list is cut into world_size contiguous segments of about
+        equal TIME (stage_weights); segment s runs on rank P-1-s, so rank 0 owns the head and assembles the video.  The
+        chunks of the single-GPU decode ([1, 4, 4, ...] latent frames) flow through the ranks as a pipeline — the causal
+        feat_cache of a conv stays on the rank that owns the conv, only the activation of the cut crosses ranks: sent
+        from a side stream (the next chunk's kernels do not wait for it) and received one chunk ahead on another.
+        Exactly the single-GPU arithmetic.  Every rank passes the same latent; returns the video on rank 0, None elsewhere."""
         import torch.distributed as dist
-        from ..distributed.ulysses import p2p_recv, p2p_send
         P, rank = dist.get_world_size(group), dist.get_rank(group)
         if P == 1:
-            return self.decode(z)
-        return self._decode_pipelined(z, group, P, rank)
+            return self.decode(z, chunks)
+        return self._decode_pipelined(z, group, P, rank, chunks, stage_ms)
 
-    def _decode_pipelined(self, z, group, P, rank):
+    def _decode_pipelined(self, z, group, P, rank, chunks=None, stage_ms=None):
         import torch.distributed as dist
-        from ..distributed.ulysses import p2p_recv, p2p_send
+        from ..distributed import collectives
         z = z.to(self.device, torch.float32).contiguous()
         C, T, H, W = z.shape
+        chunks = self._chunks(T, chunks)
         stages = self._stages()
-        cuts = partition_costs(self.stage_costs(H, W), min(P, len(stages)))
+        cuts = partition_costs(self.stage_weights(H, W, stage_ms), min(P, len(stages)))
         nseg = len(cuts) - 1
         if rank >= nseg:                                   # more ranks than stages: the rest idle
             return None
@@ -262,18 +302,80 @@ class WanVAE_:
         dst = dist.get_global_rank(group, rank - 1) if group is not None else rank - 1      # downstream: segment seg+1
         cache = [None] * (self.n_slots + 8)
         video = self._new(3, 1 + 4 * (T - 1), 8 * H, 8 * W) if seg == nseg - 1 else None
+        cuda = self.device.type == 'cuda'
+        cur = torch.cuda.current_stream(self.device) if cuda else None
+        s_send = torch.cuda.Stream(device=self.device) if cuda and video is None else None
+        s_recv = torch.cuda.Stream(device=self.device) if cuda and first != 0 else None
+
+        def post_recv(ci):
+            """the cut activation of chunk ci, received on the side stream; -> (tensor, event the compute stream waits on)"""
+            shape = self.stage_out_shape(first, chunks[ci], ci == 0, H, W)
+            if s_recv is None:
+                return collectives.recv(shape, src, self.device, group), None
+            with torch.cuda.stream(s_recv):
+                x = collectives.recv(shape, src, self.device, group)
+                ev = torch.cuda.Event()
+                ev.record(s_recv)
+            return x, ev
         if first == 0:
             x_all = self._conv('conv2', ops.vae_latent_in(z, self.mean, self.inv_std, self._new(T, H, W, C)))
-        f0 = 0
-        for i in range(T):
-            x = x_all[i:i + 1] if first == 0 else p2p_recv(src, self.device, group)
-            y = self._decoder_chunk(x, cache, first, last)
-            if video is None:
-                p2p_send(y, dst, group)
+        else:
+            nxt = post_recv(0)
+        t0, f0 = 0, 0
+        for ci, n in enumerate(chunks):
+            if first == 0:
+                x = x_all[t0:t0 + n]
             else:
+                x, ev = nxt
+                if ev is not None:
+                    cur.wait_event(ev)
+                    x.record_stream(cur)
+                if ci + 1 < len(chunks):
+                    nxt = post_recv(ci + 1)                # in flight while this chunk computes
+            y = self._decoder_chunk(x, cache, first, last)
+            if video is not None:
                 ops.vae_video_out(y, video, f0)
                 f0 += y.shape[0]
+            elif s_send is None:
+                collectives.send(y, dst, group)
+            else:
+                done = torch.cuda.Event()
+                done.record(cur)
+                with torch.cuda.stream(s_send):
+                    s_send.wait_event(done)
+                    collectives.send(y, dst, group)
+                    y.record_stream(s_send)
+            t0 += n
+        if s_send is not None:
+            cur.wait_stream(s_send)
         return video
+
+
+# measured cost per multiply-add of the decoder's kernel classes, relative to the 384- / 192-channel 3x3x3 convolutions
+# (vae_conv_kernel<4>), 1920x832 latent, 4-frame chunks — profiles/r04*_vae_stages.txt, tools/bench_vae.py --stages:
+#   narrow = the 96-channel stage (vae_conv_kernel<3>: three of four MFMA column blocks of a 128-wide tile),
+#   up   = Resample stages (time_conv 3x1x1 + the four 2x2 phase convs + interleave),
+#   attn = the per-frame attention block (qkv / proj 1x1 convs + score blocks of 2048 rows + row softmax),
+#   head = RMS_norm + SiLU + the 96 -> 3 convolution (vae_conv_kernel<1>).
+REL_MS_PER_MAC = {'wide': 1.0, 'narrow': 1.0, 'up': 1.0, 'attn': 1.0, 'head': 1.0}
+
+
+def pipeline_makespan(seg_ms_first, seg_ms_steady, n_chunks, xfer_ms=None):
+    """modelled wall time of the layer pipeline: segment s takes seg_ms_first[s] for chunk 0 (one latent frame, the
+    temporal up-samplers skipped) and seg_ms_steady[s] for every later chunk; a chunk enters segment s when it has left
+    segment s-1 (+ xfer_ms[s-1] on the link, overlapped with compute on both sides) and segment s is done with the chunk
+    before.  -> (makespan, efficiency = sum of all work / (segments x makespan))."""
+    S = len(seg_ms_steady)
+    xfer_ms = xfer_ms or [0.0] * (S - 1)
+    done = [[0.0] * n_chunks for _ in range(S)]
+    for c in range(n_chunks):
+        for s_ in range(S):
+            t = seg_ms_first[s_] if c == 0 else seg_ms_steady[s_]
+            ready = done[s_ - 1][c] + xfer_ms[s_ - 1] if s_ else 0.0
+            free = done[s_][c - 1] if c else 0.0
+            done[s_][c] = max(ready, free) + t
+    total = sum(seg_ms_first) + (n_chunks - 1) * sum(seg_ms_steady)
+    return done[-1][-1], total / (S * done[-1][-1])
 
 
 def partition_costs(costs, parts):

@@ -163,11 +163,16 @@ class WanT2V:
                 # reference text2video.py:257-259 moves the DiT to the host before the VAE decode to make room on an
                 # 80 GB device.  Here that is 28 GB over PCIe and back on the next call, for nothing, whenever the decode
                 # fits beside the resident model — which it does on 288 GB: the flag then only drops the DiT's activation
-                # workspace; the weights move only when the free memory would not hold the decode's peak.
+                # workspace; the weights move only when the free memory would not hold 1.25 x the decode's estimated peak
+                # (MOVIIGEN_FORCE_OFFLOAD=1 restores the reference's unconditional move), and a decode that still runs out
+                # of memory is retried once with the DiT on the host.
                 self.model._ws = {}
                 torch.cuda.empty_cache()
                 free_b, _ = torch.cuda.mem_get_info(self.device)
                 need_b = self.vae.decode_peak_bytes(target_shape) if hasattr(self.vae, 'decode_peak_bytes') else 32 << 30
+                need_b = need_b * 5 // 4
+                if os.environ.get('MOVIIGEN_FORCE_OFFLOAD') == '1':
+                    need_b = free_b + 1
                 if free_b > need_b:
                     logging.info(f'offload_model: {free_b / 2**30:.0f} GiB free >= {need_b / 2**30:.0f} GiB for the VAE decode '
                                  '-> the DiT stays resident (nothing is moved to the host)')
@@ -175,12 +180,22 @@ class WanT2V:
                     self.model.cpu()
                     torch.cuda.empty_cache()
                     offloaded = True
-            self.last_offloaded = offloaded
             if self.vae_parallel:    # layer-pipelined decode over all ranks, video assembled on rank 0
                 videos = self.vae.decode_pipelined(x0)
                 videos = videos if self.rank == 0 else None
             else:
-                videos = self.vae.decode(x0) if self.rank == 0 else None
+                try:
+                    videos = self.vae.decode(x0) if self.rank == 0 else None
+                except torch.cuda.OutOfMemoryError:
+                    if not offload_model or offloaded:
+                        raise
+                    logging.warning('offload_model: the VAE decode ran out of memory beside the resident DiT -> moving the '
+                                    'DiT to the host (reference text2video.py:257-259) and decoding again')
+                    self.model.cpu()
+                    torch.cuda.empty_cache()
+                    offloaded = True
+                    videos = self.vae.decode(x0)
+            self.last_offloaded = offloaded
 
         del noise, latent, sample_scheduler
         if offload_model:

@@ -38,15 +38,24 @@ else:
 rank, world = dist.get_rank(), dist.get_world_size()
 mode = os.environ.get('MOVIIGEN_TEST_LAYOUT', 'cfg_sp_fsdp')
 
-heads = 8                                                     # divisible by every Ulysses degree up to 8
-cfg = dict(model_type='t2v', patch_size=(1, 2, 2), text_len=64, in_dim=16, dim=heads * 128, ffn_dim=1536, freq_dim=64,
-           text_dim=128, out_dim=16, num_heads=heads, num_layers=3, eps=1e-6)
-m = wan.modules.WanModel(**cfg)
+if os.environ.get('MOVIIGEN_TEST_MODEL') == 'width40':
+    # the 14B model's REAL width and head count (dim 5120, 40 heads x 128, ffn 13824, 512 text keys), 2 layers, 256 tokens:
+    # what the 8-rank layouts of BASELINE configs[2] / [3] really look like — Ulysses 8 = 5 heads per rank = five ONE-head
+    # pipeline groups; cond / uncond halves x Ulysses 4 = 10 heads per rank = five 2-head groups; 8-way block shards
+    heads = 40
+    cfg = dict(model_type='t2v', patch_size=(1, 2, 2), text_len=512, in_dim=16, dim=5120, ffn_dim=13824, freq_dim=256,
+               text_dim=4096, out_dim=16, num_heads=heads, num_layers=2, eps=1e-6)
+    lat_shape = (16, 2, 16, 32)                               # grid (2, 8, 16) = 256 tokens
+else:
+    heads = 8                                                 # divisible by every Ulysses degree up to 8
+    cfg = dict(model_type='t2v', patch_size=(1, 2, 2), text_len=64, in_dim=16, dim=heads * 128, ffn_dim=1536, freq_dim=64,
+               text_dim=128, out_dim=16, num_heads=heads, num_layers=3, eps=1e-6)
+    lat_shape = (16, 2, 16, 16)                               # grid (2, 8, 8) = 128 tokens
+m = wan.modules.WanModel(**cfg, device=dev)
 m.load_state_dict(W.make_dit_params(cfg, 0))
-m.to(dev)
-lat = W.randn((16, 2, 16, 16), 20).to(dev)                   # grid (2, 8, 8) = 128 tokens
+lat = W.randn(lat_shape, 20).to(dev)
 ctx, ctx_null = W.randn((33, cfg['text_dim']), 30).to(dev), W.randn((7, cfg['text_dim']), 31).to(dev)
-L = 2 * 8 * 8
+L = lat_shape[1] * (lat_shape[2] // 2) * (lat_shape[3] // 2)
 ts = [torch.tensor([650], device=dev), torch.tensor([333], device=dev)]
 refs = [(m([lat], t=t, context=[ctx], seq_len=L)[0].clone(), m([lat], t=t, context=[ctx_null], seq_len=L)[0].clone())
         for t in ts]

@@ -17,16 +17,30 @@ from wan.modules.vae import partition_costs  # noqa: E402
 dist.init_process_group('gloo')
 rank, world = dist.get_rank(), dist.get_world_size()
 vae = wan.modules.WanVAE(state_dict=W.make_vae_params(8, 1), device='cuda:0')
-z = W.randn((16, 4, 6, 10), 41)
+z = W.randn((16, 10, 6, 10), 41)                        # 10 latent frames: chunks [1, 4, 4, 1] — the single-GPU chunk list
 ref = vae.decode([z])[0]
+assert vae.model._chunks(10) == [1, 4, 4, 1]
 out = vae.decode_pipelined([z])[0]
+# cut by "measured" stage times instead of the cost model (any positive weights must give the same video), and the
+# reference's one-frame chunks
+n_st = len(vae.model._stages())
+out2 = vae.model.decode_pipelined(z, stage_ms=[1.0 + (i % 3) for i in range(n_st)])
+out3 = vae.model.decode_pipelined(z, chunks=[1] * 10)
 if rank == 0:
     assert out is not None and torch.equal(out, ref), (out - ref).abs().max().item()
-    costs = vae.model.stage_costs(6, 10)
+    assert torch.equal(out2, ref) and torch.equal(out3, ref)
+    costs = vae.model.stage_weights(6, 10)
     cuts = partition_costs(costs, world)
     assert cuts[0] == 0 and cuts[-1] == len(costs) and all(b > a for a, b in zip(cuts, cuts[1:]))
+    # the shape the receiver of a cut allocates == what the upstream stages really produce
+    m = vae.model
+    x = torch.zeros(1, 6, 10, 16, device='cuda:0')
+    for last in (1, 5, 8, 12, n_st):                    # first chunk: run the stages [0, last) and compare
+        y = m._decoder_chunk(x, [None] * (m.n_slots + 8), 0, last)
+        assert tuple(y.shape) == m.stage_out_shape(last, 1, True, 6, 10), (last, y.shape)
+    assert m.stage_out_shape(n_st, 4, False, 6, 10) == (16, 48, 80, 3)
 else:
-    assert out is None
+    assert out is None and out2 is None and out3 is None
 print(f'VAEPIPE_OK rank{rank}/{world}', flush=True)
 dist.barrier()
 dist.destroy_process_group()

@@ -1058,17 +1058,19 @@ def test_cfg_parallel_one_gpu(world):
         assert f'CFGP_OK rank{k}/{world}' in r.stdout
 
 
-def _run_hybrid(world, backend, layout, port, transport='torch'):
+def _run_hybrid(world, backend, layout, port, transport='torch', model=None):
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MOVIIGEN_TEST_BACKEND=backend, MOVIIGEN_TEST_LAYOUT=layout, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    if model:
+        env['MOVIIGEN_TEST_MODEL'] = model
     if transport != 'torch':            # rccl_direct: the C-ABI collectives on the library's own communicator
         env['MOVIIGEN_SP_TRANSPORT'] = transport        # (mg_sp_all_to_all, ...); peer_copy: one-sided copies into IPC-mapped buffers
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={world}',
                         '--master-addr', '127.0.0.1', '--master-port', str(port),
-                        os.path.join(root, 'tests', 'dist_hybrid_worker.py')], capture_output=True, text=True, timeout=900,
+                        os.path.join(root, 'tests', 'dist_hybrid_worker.py')], capture_output=True, text=True, timeout=1500,
                        env=env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     for k in range(world):
@@ -1081,6 +1083,17 @@ def test_config3_composition_one_gpu(world, layout):
     cuda:0 = 2 x Ulysses 2 x 4-way shards), and Ulysses over all ranks + shards; pipelined packed exchange at
     depth 1, 2 and default; bit-identical to the unsharded forwards."""
     _run_hybrid(world, 'gloo', layout, 29600 + world + (0 if layout == 'cfg_sp_fsdp' else 10))
+
+
+@pytest.mark.parametrize('layout', ['sp_fsdp', 'cfg_sp_fsdp'], ids=['ulysses_sp8_fsdp8', 'cfg2_ulysses_sp4_fsdp8'])
+def test_eight_rank_layouts_real_heads_one_gpu(layout):
+    """the 8-rank layouts of BASELINE configs[2] / configs[3] instantiated with the model's REAL width and head count
+    (dim 5120, 40 heads, ffn 13824; 2 layers, 256 tokens; 8 gloo ranks sharing cuda:0): `ulysses_sp8` = 5 heads per rank
+    = five one-head pipeline groups (reference scripts/inference/generate.py:216-229, 40 % 8 == 0), and
+    `cfg2 x ulysses_sp4 x fsdp8` = cond / uncond halves x Ulysses 4 (ten heads per rank in five 2-head groups) x block
+    shards over all eight ranks (reference text2video.py:97-108) — both bit-identical to the unsharded forwards at
+    pipeline depth 1, 2 and default."""
+    _run_hybrid(8, 'gloo', layout, 29640 + (0 if layout == 'sp_fsdp' else 1), model='width40')
 
 
 def test_peer_copy_transport_one_gpu():
@@ -1263,11 +1276,15 @@ def test_attention_lse_and_merge(dev):
         ops.attention_hd128_lse(q, kp, vp, out, torch.empty(3, dtype=torch.float32, device=dev), Lk, heads, 1.0)
 
 
-@pytest.mark.parametrize('world,extra,plain', [(2, [], False), (4, [], True), (2, ['--no-cfg-parallel'], True)])
+@pytest.mark.parametrize('world,extra,plain', [(2, [], False), (4, [], True), (2, ['--no-cfg-parallel'], True),
+                                               (4, ['--dit-fsdp', '--vae-parallel', '--transport', 'peer_copy'], False)],
+                         ids=['cfg2_torchrun', 'cfg2_sp2_plain', 'sp2_plain', 'configs3_form_cfg2_sp2_fsdp4_vaepipe_peercopy'])
 def test_bench_multirank_code_path(world, extra, plain):
-    """bench.py's N > 1 branches (CFG-parallel halves x Ulysses, or Ulysses over all ranks) on one GPU through
-    gloo, tiny workload: must print ONE JSON line with the contract keys.  plain: `python bench.py --gpus N` WITHOUT
-    torch.distributed.run — bench.py launches its own ranks; else the driver's torchrun form."""
+    """bench.py's N > 1 branches (CFG-parallel halves x Ulysses, or Ulysses over all ranks; block-sharded weights,
+    pipelined VAE tail, exchange transport) on one GPU through gloo, tiny workload: must print ONE JSON line with the
+    contract keys.  plain: `python bench.py --gpus N` WITHOUT torch.distributed.run — bench.py launches its own ranks;
+    else the driver's torchrun form.  The last case is the command form of BASELINE configs[3] (`--gpus 8 --dit-fsdp` prints
+    `cfg2 x ulysses_sp4 x fsdp8`) at 4 ranks."""
     import json
     import os
     import subprocess
@@ -1288,11 +1305,18 @@ def test_bench_multirank_code_path(world, extra, plain):
               'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'sec_per_video', 'vae_decode'):
         assert k in d, k
     assert d['n_gpus'] == world and d['scaling'] == 'strong' and d['value'] > 0
-    want = f'ulysses_sp{world}' if extra else (f'cfg2 x ulysses_sp{world // 2}')
-    assert d['config']['parallelism'] == want, d['config']
+    want = f'ulysses_sp{world}' if '--no-cfg-parallel' in extra else (f'cfg2 x ulysses_sp{world // 2}')
+    fsdp = '--dit-fsdp' in extra
+    assert d['config']['parallelism'] == want + (f' x fsdp{world}' if fsdp else ''), d['config']
     # what the line says about the ranks: gloo plumbing here (rccl_ranks 0), one entry per rank, overlap measured
     # whenever the layout has a per-layer exchange (cfg2 on 2 ranks has none)
-    assert d['rccl_ranks'] == 0 and 'gloo' in d['transport'] and len(d['rank_devices']) == world
+    assert d['rccl_ranks'] == 0 and 'gloo' in d['transport']['used'] and len(d['rank_devices']) == world
+    assert d['transport']['requested'] == ('peer_copy' if 'peer_copy' in extra else 'torch')
+    if fsdp:
+        f = d['fsdp']
+        assert f['ranks'] == world and f['gathers_per_step'] >= 2 and f['gather_ms_per_step'] > 0 and 0 <= f['exposed_ms_per_step']
+        assert f['gathered_bytes_per_block'] >= 2 * (4 * 5120 * 5120 * 2 + 2 * 5120 * 13824)     # bf16 GEMM weights of one 14B-width block
+    assert ('pipeline over' in d['vae_decode_layout']) == ('--vae-parallel' in extra)
     assert sorted(e['rank'] for e in d['rank_devices']) == list(range(world))
     if want != 'cfg2 x ulysses_sp1':
         ov = d['overlap']

@@ -19,6 +19,7 @@ ap.add_argument('--size', default='1920x832')
 ap.add_argument('--frames', type=int, default=81)
 ap.add_argument('--chunk', type=int, default=1, help='latent frames per decoder chunk after the first')
 ap.add_argument('--mode', default='exact', choices=('exact', 'bf16x3'), help='bf16x3: the opt-in split-bf16 convolutions (not the reference arithmetic)')
+ap.add_argument('--stages', action='store_true', help='also time every decoder stage (first chunk / steady chunk) and model the layer pipeline of decode_pipelined for 2 / 4 / 8 ranks')
 ap.add_argument('--upconv', default='phases', choices=('phases', 'gather'), help="the convs behind a 2x upsample: four 2x2 phase convs / one 3x3 through the upsample")
 args = ap.parse_args()
 Wd, Hd = (int(v) for v in args.size.split('x'))
@@ -43,3 +44,56 @@ flops = (1065.8e12 if args.upconv == 'phases' else 1116.5e12) * (Wd * Hd * args.
 print(json.dumps({'metric': 'vae_decode_sec', 'value': dt, 'second_decode_sec': dt_warm, 'upconv': args.upconv, 'mode': args.mode, 'size': args.size, 'frames': args.frames, 'chunks': chunks[:3],
                   'tflops_fp32': flops / dt / 1e12, 'fp32_mfma_peak_tflops': 157.3, 'frac': flops / dt / 157.3e12,
                   'finite': bool(torch.isfinite(video).all().item()), 'peak_mem_gb': torch.cuda.max_memory_allocated() / 2**30}))
+
+if args.stages:
+    # per-stage milliseconds (HIP events around every _run_stage call of one more decode), the cost per MAC of each kernel
+    # class relative to the wide 3x3x3 convolutions (-> wan/modules/vae.py REL_MS_PER_MAC), and the modelled makespan of
+    # the layer pipeline cut by these times (WanVAE_.decode_pipelined)
+    from wan.modules.vae import partition_costs, pipeline_makespan
+    m = vae.model
+    ev, orig = [], m._run_stage
+
+    def timed(stage, x, cache, idx):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        y = orig(stage, x, cache, idx)
+        b.record()
+        ev.append((a, b))
+        return y
+    m._run_stage = timed
+    m.decode(z, chunks=chunks)
+    torch.cuda.synchronize()
+    m._run_stage = orig
+    stages = m._stages()
+    S = len(stages)
+    ms = [[a.elapsed_time(b) for a, b in ev[c * S:(c + 1) * S]] for c in range(len(chunks))]
+    first, steady = ms[0], [sum(ms[c][i] for c in range(1, len(chunks)) if chunks[c] == chunks[1]) / max(1, sum(1 for c in range(1, len(chunks)) if chunks[c] == chunks[1])) for i in range(S)]
+    macs = m.stage_costs(Hd // 8, Wd // 8)
+    cls = {}
+    base = m.P['decoder.head.0.gamma'].numel()
+    for (kind, pre, _), c, t in zip(stages, macs, steady):
+        k = kind
+        if kind in ('conv1', 'res'):
+            k = 'narrow' if m.P[pre + ('.weight' if kind == 'conv1' else 'residual.6.weight')].shape[0] == base else 'wide'
+        a = cls.setdefault(k, [0.0, 0.0])
+        a[0] += t
+        a[1] += c * chunks[1]
+    rel = {k: (v[0] / v[1]) / (cls['wide'][0] / cls['wide'][1]) for k, v in cls.items()}
+    print('stage                                kind   first_ms  steady_ms  GMAC/frame')
+    for (kind, pre, _), a, b, c in zip(stages, first, steady, macs):
+        print(f'{pre:36s} {kind:6s} {a:9.2f} {b:10.2f} {c / 1e9:11.1f}')
+    print('REL_MS_PER_MAC =', {k: round(v, 3) for k, v in rel.items()})
+    h, w = Hd // 8, Wd // 8
+    for P in (2, 4, 8):
+        for name, weights in (('measured ms', steady), ('MACs', macs)):
+            cuts = partition_costs(weights, P)
+            seg_f = [sum(first[a:b]) for a, b in zip(cuts, cuts[1:])]
+            seg_s = [sum(steady[a:b]) for a, b in zip(cuts, cuts[1:])]
+            # bytes over a cut per steady chunk at ~45 GB/s effective per xGMI link (one direction, one peer)
+            xfer = []
+            for cpos in cuts[1:-1]:
+                f, hh, ww, cc = m.stage_out_shape(cpos, chunks[1], False, h, w)
+                xfer.append(f * hh * ww * cc * 4 / 45e9 * 1e3)
+            mk, eff = pipeline_makespan(seg_f, seg_s, len(chunks), xfer)
+            print(f'P={P} cut by {name:11s}: cuts {cuts}  steady segment ms {[round(v) for v in seg_s]}  transfer ms/chunk {[round(v, 1) for v in xfer]}  '
+                  f'modelled makespan {mk / 1e3:.2f} s  (single GPU {(sum(first) + (len(chunks) - 1) * sum(steady)) / 1e3:.2f} s, efficiency {eff:.2f})')
