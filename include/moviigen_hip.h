@@ -125,10 +125,13 @@ int mg_attn_fwd_bf16_hd128_lse(const uint16_t* q, int64_t ldq, const uint16_t* k
 /* Same operator for a q that ALREADY carries the factor scale*log2(e) (mg_rmsnorm_rope_bf16 with out_scale: the factor
  * enters before q's one rounding to bf16, so nothing is rounded twice) — the form WanModel.forward uses.  With the
  * default kernel a score then IS its base-2 exponent (no per-score multiply-add).  lse may be NULL; when given it is
- * the natural-log log-sum-exp of the true scaled scores, as above. */
+ * the natural-log log-sum-exp of the true scaled scores, as above.
+ * reserve_cus >= 0: compute units the (persistent, one-workgroup-per-CU) launch leaves free, rounded up to a multiple of
+ * 8 = one per XCD — room for a kernel on another stream (RCCL's all-to-all of the next head group under sequence
+ * parallelism: a persistent workgroup holds its CU's whole register file until the launch ends).  0 = all CUs. */
 int mg_attn_fwd_bf16_hd128_prescaled(const uint16_t* q, int64_t ldq, const uint16_t* kp, const uint16_t* vp,
                                      uint16_t* o, int64_t ldo, float* lse, int64_t Lq, int64_t Lk, int heads,
-                                     void* stream);
+                                     int reserve_cus, void* stream);
 
 /* x[r][c] += float(y[r][c]) * gate[c]: the gated residual update of wan/modules/model.py:301-302,306,308-309 as a
  * stand-alone kernel (x fp32 [rows][dim] row stride ldx; y bf16 row stride ldy; gate fp32 [dim] or NULL = 1).
@@ -308,7 +311,8 @@ int mg_vae_upconv_phases_f32(const float* x, int T, int H, int W, int Cin, const
  *   MG_VAE_EXACT  = v_mfma_f32_32x32x2_f32, bitwise an fmaf chain — the reference's fp32 arithmetic (vae.py:623,658);
  *   MG_VAE_BF16X3 = split bf16 x 3: every fp32 operand as hi + lo bf16 (16 mantissa bits), W_hi.X_hi + W_hi.X_lo + W_lo.X_hi
  *       on the bf16 MFMA with fp32 accumulation: ~1e-5 relative to the exact mode per convolution, NOT the reference's
- *       arithmetic, opt-in (WanVAE(mode='bf16x3')) and never what bench.py measures.  mg_vae_attn_f32 is always exact. */
+ *       arithmetic, opt-in (WanVAE(mode='bf16x3')) and never what bench.py measures.  mg_vae_attn_f32 and convolutions
+ *       with Cout <= 4 (the decoder head, on v_mfma_f32_4x4x1_16B_f32) are exact in either mode. */
 #define MG_VAE_EXACT 0
 #define MG_VAE_BF16X3 1
 

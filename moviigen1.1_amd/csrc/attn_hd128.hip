@@ -71,7 +71,8 @@ __global__ __launch_bounds__(256) void pack_kv_kernel(const uint16_t* __restrict
 int mg_attn_w64_launch(const uint16_t* q, int64_t ldq, const uint16_t* kp, const uint16_t* vp, uint16_t* o, int64_t ldo,
                        int64_t Lq, int64_t Lk, int heads, float c_log2, int nqb, float* lse, hipStream_t st);
 int mg_attn_m16_launch(const uint16_t* q, int64_t ldq, const uint16_t* kp, const uint16_t* vp, uint16_t* o, int64_t ldo,
-                       int64_t Lq, int64_t Lk, int heads, float c_log2, int prescaled, int nqb, float* lse, hipStream_t st);
+                       int64_t Lq, int64_t Lk, int heads, float c_log2, int prescaled, int nqb, float* lse, int reserve_cus,
+                       hipStream_t st);
 
 static int g_attn_variant = 0;      // 0 = m16 (default), 3 = w64 (round-2 kernel, A/B partner)
 extern "C" void mg_attn_set_variant(int v) { g_attn_variant = v == 3 ? 3 : 0; }
@@ -87,9 +88,9 @@ extern "C" int mg_pack_kv_bf16(const uint16_t* k, int64_t ldk, const uint16_t* v
 }
 
 static int attn_fwd_impl(const uint16_t* q, int64_t ldq, const uint16_t* kp, const uint16_t* vp, uint16_t* o, int64_t ldo,
-                         float* lse, int64_t Lq, int64_t Lk, int heads, float scale, int prescaled, void* stream) {
+                         float* lse, int64_t Lq, int64_t Lk, int heads, float scale, int prescaled, int reserve_cus, void* stream) {
     if (!q || !kp || !vp || !o) return MG_ERR_ARG;
-    if (Lq < 0 || Lk <= 0 || heads <= 0) return MG_ERR_SHAPE;
+    if (Lq < 0 || Lk <= 0 || heads <= 0 || reserve_cus < 0) return MG_ERR_SHAPE;
     if ((ldq & 7) || (ldo & 3)) return MG_ERR_SHAPE;
     if (((uintptr_t)q & 15) || ((uintptr_t)kp & 15) || ((uintptr_t)vp & 15) || ((uintptr_t)o & 7)) return MG_ERR_SHAPE;
     if (Lq == 0) return MG_OK;
@@ -100,21 +101,21 @@ static int attn_fwd_impl(const uint16_t* q, int64_t ldq, const uint16_t* kp, con
     hipStream_t st = (hipStream_t)stream;
     if (g_attn_variant == 3)    // the round-2 kernel knows no pre-scaled q other than "its own factor is 1"
         return mg_attn_w64_launch(q, ldq, kp, vp, o, ldo, Lq, Lk, heads, prescaled ? 1.0f : c_log2, nqb, lse, st);
-    return mg_attn_m16_launch(q, ldq, kp, vp, o, ldo, Lq, Lk, heads, c_log2, prescaled, nqb, lse, st);
+    return mg_attn_m16_launch(q, ldq, kp, vp, o, ldo, Lq, Lk, heads, c_log2, prescaled, nqb, lse, reserve_cus, st);
 }
 
 extern "C" int mg_attn_fwd_bf16_hd128_lse(const uint16_t* q, int64_t ldq, const uint16_t* kp, const uint16_t* vp,
                                           uint16_t* o, int64_t ldo, float* lse, int64_t Lq, int64_t Lk, int heads,
                                           float scale, void* stream) {
-    return attn_fwd_impl(q, ldq, kp, vp, o, ldo, lse, Lq, Lk, heads, scale, 0, stream);
+    return attn_fwd_impl(q, ldq, kp, vp, o, ldo, lse, Lq, Lk, heads, scale, 0, 0, stream);
 }
 extern "C" int mg_attn_fwd_bf16_hd128(const uint16_t* q, int64_t ldq, const uint16_t* kp, const uint16_t* vp,
                                       uint16_t* o, int64_t ldo, int64_t Lq, int64_t Lk, int heads, float scale,
                                       void* stream) {
-    return attn_fwd_impl(q, ldq, kp, vp, o, ldo, nullptr, Lq, Lk, heads, scale, 0, stream);
+    return attn_fwd_impl(q, ldq, kp, vp, o, ldo, nullptr, Lq, Lk, heads, scale, 0, 0, stream);
 }
 extern "C" int mg_attn_fwd_bf16_hd128_prescaled(const uint16_t* q, int64_t ldq, const uint16_t* kp, const uint16_t* vp,
                                                 uint16_t* o, int64_t ldo, float* lse, int64_t Lq, int64_t Lk, int heads,
-                                                void* stream) {
-    return attn_fwd_impl(q, ldq, kp, vp, o, ldo, lse, Lq, Lk, heads, 1.0f, 1, stream);
+                                                int reserve_cus, void* stream) {
+    return attn_fwd_impl(q, ldq, kp, vp, o, ldo, lse, Lq, Lk, heads, 1.0f, 1, reserve_cus, stream);
 }

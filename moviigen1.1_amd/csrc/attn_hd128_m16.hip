@@ -456,23 +456,28 @@ __global__ __launch_bounds__(M16_THREADS, 1) void attn_hd128_m16_kernel(
         };
         if (attempt) {
             // ------------------------------------------------------------------------------------------
-            // reference sweep (only after a flagged pass): TRUE row maxima.  S^T of every tile, K tiles
-            // double-buffered in slots 0 / 1, one barrier per tile, no V, no exponentials.
+            // reference sweep (only after a flagged pass): TRUE row maxima.  S^T of every tile (64 MFMAs
+            // per wave and tile), one barrier per tile, no V, no exponentials.
             // ------------------------------------------------------------------------------------------
             float mx[4] = {-1e30f, -1e30f, -1e30f, -1e30f};
+            // K tiles ride a ring of all six 16 KiB slots, four tiles ahead (tile t in slot t % 6; indices past the end
+            // are clamped: a redundant reload into a slot nobody reads), so a tile's DMA latency is covered by the S^T of
+            // three others; vmcnt(12) = this wave's pieces of the OLDEST of the four tiles in flight have landed
 #pragma unroll
-            for (int n = 0; n < 4; ++n) dma_k(0, 0, n);
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) dma_k(a, a, n);
             for (int t = 0; t < T; ++t) {
-                fence();                        // K(t) landed; everyone is past S(t-1): slot (t+1)&1 is free
-                if (t + 1 < T) {
+                asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                __syncthreads();                // K(t) visible to all; everyone is past S(t-1): slot (t+4) % 6 = (t-2) % 6 is free
 #pragma unroll
-                    for (int n = 0; n < 4; ++n) dma_k(t + 1, (t + 1) & 1, n);
-                }
+                for (int n = 0; n < 4; ++n) dma_k(t + 4, (t + 4) % 6, n);
                 const int lim = t == T - 1 ? last_lim : 64;
-                bare_S(KB0{}, t & 1, lim);
-                bare_S(KB1{}, t & 1, lim);
+                bare_S(KB0{}, t % 6, lim);
+                bare_S(KB1{}, t % 6, lim);
                 tile_max(mx);
             }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the clamped tail loads must not land under the pass below
             set_reference(mx, 0.f);
             __syncthreads();                    // the last S reads are done before the pass below refills slots 0 / 1
             reset();
@@ -629,11 +634,17 @@ void mg_attn_m16_hooks(int dbg, unsigned long long* prof, unsigned* flagcnt) { g
 
 // c_log2 = scale*log2(e) of the scores; prescaled != 0: q already carries that factor (mg_rmsnorm_rope_bf16 out_scale).
 // kp must be in the m16 row order (mg_pack_kv_bf16 with the m16 kernel selected).
+// reserve_cus: CUs this launch leaves free (rounded up to a multiple of the 8 XCDs: workgroups are dealt round-robin over
+// the XCDs, so 8 = one CU per XCD).  A persistent workgroup owns its CU's whole register file for the length of the
+// launch: a kernel on another stream — RCCL's all-to-all of the next head group (wan/distributed/ulysses.py) — can only
+// run on CUs this grid does not occupy.
 int mg_attn_m16_launch(const uint16_t* q, int64_t ldq, const uint16_t* kp, const uint16_t* vp, uint16_t* o, int64_t ldo,
-                       int64_t Lq, int64_t Lk, int heads, float c_log2, int prescaled, int nqb, float* lse, hipStream_t st) {
+                       int64_t Lq, int64_t Lk, int heads, float c_log2, int prescaled, int nqb, float* lse, int reserve_cus,
+                       hipStream_t st) {
     int n_cu = mg_cu_count();
     if (n_cu < 0) return MG_ERR_LAUNCH;
     n_cu &= ~7;                                         // one workgroup per CU (96 KiB LDS), a multiple of the 8 XCDs
+    n_cu -= (reserve_cus + 7) & ~7;
     if (n_cu < 8) n_cu = 8;
     const int total = nqb * heads;
     const unsigned grid = total <= n_cu ? (unsigned)total : (unsigned)n_cu;   // persistent when there is more work than CUs

@@ -290,7 +290,7 @@ static void test_attn(int64_t Lq, int64_t Lk, int heads, int nsamp, bool timeit,
         new (&dqs) Dev<uint16_t>(qs);
     }
     auto run = [&]() {
-        return prescaled ? mg_attn_fwd_bf16_hd128_prescaled(dqs.p, ld, dkp.p, dvp.p, dout.p, ld, nullptr, Lq, Lk, heads, 0)
+        return prescaled ? mg_attn_fwd_bf16_hd128_prescaled(dqs.p, ld, dkp.p, dvp.p, dout.p, ld, nullptr, Lq, Lk, heads, 0, 0)
                          : mg_attn_fwd_bf16_hd128(dq.p, ld, dkp.p, dvp.p, dout.p, ld, Lq, Lk, heads, scale, 0);
     };
     rc |= run();
@@ -372,6 +372,7 @@ static void attn_ab(int64_t L, int heads, int data, const std::vector<int>& vari
     }
     Dev<uint16_t> dq(q), dk(k), dv(v), dkp((size_t)npk), dvp((size_t)npk), dout((size_t)L * ld);
     Dev<unsigned> cnt(2);
+    const int reserve = getenv("MG_ATTN_RESERVE_CUS") ? atoi(getenv("MG_ATTN_RESERVE_CUS")) : 0;   // CUs left free by the pre-scaled entry
     const float scale = 1.f / sqrtf(128.f);
     std::vector<uint16_t> qs(q.size());          // variants >= 10: the pre-scaled entry on bf16(q * scale*log2e)
     for (size_t i = 0; i < q.size(); ++i) qs[i] = f2bf(bf2f(q[i]) * scale * 1.4426950408889634f);
@@ -381,30 +382,37 @@ static void attn_ab(int64_t L, int heads, int data, const std::vector<int>& vari
     mg_attn_w64_flag_counter(cnt.p);
     const double flop = 4.0 * L * L * 128 * heads;
     printf("attn_ab L=%lld heads=%d data=%d (%s)\n", (long long)L, heads, data, attn_ab_data_name(data));
-    // reference rows (double), sampled once
+    // reference rows (double), sampled once — one set per entry point: the general entry attends with q and `scale`, the
+    // pre-scaled entry with the operand it is GIVEN, bf16(q * scale * log2 e) (here a second rounding of q; in the DiT the
+    // factor enters before q's only rounding), whose scores are base-2 exponents.  Each kernel is held to its own operands.
     const int nsamp = 12;
     std::vector<int64_t> sq(nsamp); std::vector<int> sh(nsamp);
-    std::vector<std::vector<double>> ref(nsamp, std::vector<double>(128));
+    std::vector<std::vector<double>> ref[2] = {std::vector<std::vector<double>>(nsamp, std::vector<double>(128)),
+                                               std::vector<std::vector<double>>(nsamp, std::vector<double>(128))};
     std::vector<double> sc(L);
-    double ref_max = 0;
+    double ref_max[2] = {0, 0};
     for (int it = 0; it < nsamp; ++it) {
         rng_state = rng_state * 6364136223846793005ull + 1442695040888963407ull;
         sq[it] = it < 2 ? it : (it < 4 ? L - 1 - it : (int64_t)((rng_state >> 20) % (uint64_t)L));
         sh[it] = (int)((rng_state >> 50) % (uint64_t)heads);
-        double mx = -1e300;
-        for (int64_t j = 0; j < L; ++j) {
-            double a = 0;
-            for (int d = 0; d < 128; ++d) a += (double)bf2f(q[(size_t)sq[it] * ld + sh[it] * 128 + d]) * bf2f(k[(size_t)j * ld + sh[it] * 128 + d]);
-            sc[j] = a * scale;
-            mx = fmax(mx, sc[j]);
-        }
-        double den = 0;
-        for (int64_t j = 0; j < L; ++j) { sc[j] = exp(sc[j] - mx); den += sc[j]; }
-        for (int d = 0; d < 128; ++d) {
-            double a = 0;
-            for (int64_t j = 0; j < L; ++j) a += sc[j] * bf2f(v[(size_t)j * ld + sh[it] * 128 + d]);
-            ref[it][d] = a / den;
-            ref_max = fmax(ref_max, fabs(ref[it][d]));
+        for (int pre = 0; pre < 2; ++pre) {
+            const std::vector<uint16_t>& qq = pre ? qs : q;
+            const double mul = pre ? 0.6931471805599453 : (double)scale;
+            double mx = -1e300;
+            for (int64_t j = 0; j < L; ++j) {
+                double a = 0;
+                for (int d = 0; d < 128; ++d) a += (double)bf2f(qq[(size_t)sq[it] * ld + sh[it] * 128 + d]) * bf2f(k[(size_t)j * ld + sh[it] * 128 + d]);
+                sc[j] = a * mul;
+                mx = fmax(mx, sc[j]);
+            }
+            double den = 0;
+            for (int64_t j = 0; j < L; ++j) { sc[j] = exp(sc[j] - mx); den += sc[j]; }
+            for (int d = 0; d < 128; ++d) {
+                double a = 0;
+                for (int64_t j = 0; j < L; ++j) a += sc[j] * bf2f(v[(size_t)j * ld + sh[it] * 128 + d]);
+                ref[pre][it][d] = a / den;
+                ref_max[pre] = fmax(ref_max[pre], fabs(ref[pre][it][d]));
+            }
         }
     }
     for (int r = 0; r < rounds; ++r)
@@ -417,7 +425,7 @@ static void attn_ab(int64_t L, int heads, int data, const std::vector<int>& vari
             cnt.zero();
             CK(hipMemset(dout.p, 0xff, dout.n * 2));
             auto run = [&]() {
-                return var >= 10 ? mg_attn_fwd_bf16_hd128_prescaled(dqs.p, ld, dkp.p, dvp.p, dout.p, ld, nullptr, L, L, heads, 0)
+                return var >= 10 ? mg_attn_fwd_bf16_hd128_prescaled(dqs.p, ld, dkp.p, dvp.p, dout.p, ld, nullptr, L, L, heads, reserve, 0)
                                  : mg_attn_fwd_bf16_hd128(dq.p, ld, dkp.p, dvp.p, dout.p, ld, L, L, heads, scale, 0);
             };
             rc |= run();
@@ -426,13 +434,14 @@ static void attn_ab(int64_t L, int heads, int data, const std::vector<int>& vari
             float ms = time_ms([&] { run(); }, 3);
             auto got = dout.host();
             double err = rc ? 1e9 : 0;
+            const int pre = var >= 10;
             for (int it = 0; it < nsamp; ++it)
                 for (int d = 0; d < 128; ++d)
-                    err = fmax(err, fabs(bf2f(got[(size_t)sq[it] * ld + sh[it] * 128 + d]) - ref[it][d]));
-            const bool ok = err <= 2e-2 * fmax(ref_max, 1e-3);
+                    err = fmax(err, fabs(bf2f(got[(size_t)sq[it] * ld + sh[it] * 128 + d]) - ref[pre][it][d]));
+            const bool ok = err <= 2e-2 * fmax(ref_max[pre], 1e-3);
             if (!ok) ++n_fail;
             printf("  [%s] variant %d round %d: %.3f ms  %.1f TFLOP/s  flagged blocks %u (exact loop %u) of %lld  max_err %.3e (ref max %.3e)\n",
-                   ok ? "PASS" : "FAIL", var, r, ms, flop / (ms * 1e-3) / 1e12, flagged, to_exact, (long long)((L + 255) / 256) * heads, err, ref_max);
+                   ok ? "PASS" : "FAIL", var, r, ms, flop / (ms * 1e-3) / 1e12, flagged, to_exact, (long long)((L + 255) / 256) * heads, err, ref_max[pre]);
             fflush(stdout);
         }
     mg_attn_w64_flag_counter(nullptr);

@@ -9,6 +9,11 @@
 // voxel is then a K-contiguous run of Cin floats, exactly like a GEMM row, and the output row of
 // a voxel is N-contiguous.  Weights are repacked once to [Cout][kt][kh][kw][Cin].
 //
+// NB = 0: the Cout <= 4 form (the decoder head, 96 -> 3): same 128-voxel tile and gather, 4 weight rows, and the
+// contraction on v_mfma_f32_4x4x1_16B_f32 — 16 independent 4 couts x 4 voxels outer products per instruction: lanes 0-31
+// carry the wave's 32 voxels for the even float4 of every 8 channels, lanes 32-63 the same voxels for the odd one, and the
+// two halves are added once at the end.  8 cycles per k instead of 64: the 32x32 tile burned 29 of its 32 cout columns.
+//
 // Tile: 128 voxels x (32*NB) couts x 32 channels per step, 4 waves, wave w owns voxels
 // [32w,32w+32) x all NB cout blocks (NB x f32x16 accumulators).  MFMA A-operand = weights
 // (row = cout), B-operand = voxels, so a lane owns ONE voxel and 4 consecutive couts per
@@ -36,6 +41,7 @@ struct ConvArgs {
     const float* w; int64_t ldw; const float* bias; int Cout; int kt, kh, kw; int up2;
     const float* residual; float* out; int64_t ldo; int Ho, Wo; int64_t M; float out_scale;
     int phases = 0; int64_t w_phase_stride = 0;      // phases: blockIdx.z = 2 py + px is one of the four 2x2 phase convolutions (below)
+    int ksplit = 0; int64_t part_stride = 0;         // ksplit > 1 (1x1x1 GEMMs only): blockIdx.z = K slice, raw partial sums go to out + z * part_stride
 };
 
 // Output epilogue shared by both conv kernels: lane (l31, g) owns voxel row m and, per cout block nb and quad rq, the four
@@ -98,7 +104,9 @@ MG_DEV void cv_epilogue(const ConvArgs& a, const f32x16_t (&acc)[NB], int64_t m_
 // NOT the reference's arithmetic: results agree with the exact mode to ~1e-5 relative (test_vae_fast_mode), never the default.
 template <int NB, bool FAST = false>
 __global__ __launch_bounds__(CV_THREADS) void vae_conv_kernel(const ConvArgs a) {
-    constexpr int BN = 32 * NB;
+    constexpr int BN = NB ? 32 * NB : 4;
+    constexpr int NW = NB ? NB : 1;                   // weight rows a thread stages per chunk (NB = 0: threads 0-31 stage the 4 rows)
+    static_assert(NB || !FAST, "the Cout <= 4 form is exact only");
     __shared__ __attribute__((aligned(16))) float smem[2 * (CV_BM + BN) * CV_LDS];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -143,14 +151,14 @@ __global__ __launch_bounds__(CV_THREADS) void vae_conv_kernel(const ConvArgs a) 
     //   * a tap that falls into the zero padding (space, or time before the first cached frame) points at a page of zeros
     //     instead of being masked: no select, no multiply, no branch around the load;
     //   * chunk coordinates advance by counters, not divisions.
-    float4 ra[4], rw[NB];
+    float4 ra[4], rw[NW];
     const float* pa[4];                     // voxel rows of the tap being loaded (or the zero page)
-    const float* pw[NB];                    // weight rows, advanced by Cin per tap
+    const float* pw[NW];                    // weight rows, advanced by Cin per tap
     int ld_cc = 0, ld_dt = 0, ld_dy = 0, ld_dx = 0;                 // coordinates of the NEXT chunk to load (wave-uniform)
     const float* const base_neg = a.cache ? a.cache : a.x;          // frames before the chunk: the cache, if any
     const int has_cache = a.cache != nullptr;
 #pragma unroll
-    for (int i = 0; i < NB; ++i) pw[i] = wbase + (int64_t)min(n0 + (tid >> 3) + 32 * i, a.Cout - 1) * a.ldw;   // rows >= Cout: never stored
+    for (int i = 0; i < NW; ++i) pw[i] = wbase + (int64_t)min(n0 + (tid >> 3) + 32 * i, a.Cout - 1) * a.ldw;   // rows >= Cout: never stored
     // Per row, once per tile: which temporal / vertical / horizontal tap offsets stay inside the tensor (bits dt | dy<<3 |
     // dx<<6); a tap is valid when its three bits are set.  For the convolutions without the folded 2x upsample the row
     // pointer of a tap is then `frame base of the row` (recomputed when dt changes: every kh*kw taps) + a WAVE-UNIFORM
@@ -216,14 +224,14 @@ __global__ __launch_bounds__(CV_THREADS) void vae_conv_kernel(const ConvArgs a) 
             ra[i] = make_float4(t[0], t[1], t[2], t[3]);
         }
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
+        for (int i = 0; i < NW; ++i) {
             const f32x4_t t = *(const f32x4_t*)(c_ok ? pw[i] + c : g_cv_zero_page);
             rw[i] = make_float4(t[0], t[1], t[2], t[3]);
         }
         if (++ld_cc == ncc) {
             ld_cc = 0;
 #pragma unroll
-            for (int i = 0; i < NB; ++i) pw[i] += a.Cin;
+            for (int i = 0; i < NW; ++i) pw[i] += a.Cin;
             if (++ld_dx == a.kw) {
                 ld_dx = 0;
                 if (++ld_dy == a.kh) { ld_dy = 0; ++ld_dt; }
@@ -251,28 +259,54 @@ __global__ __launch_bounds__(CV_THREADS) void vae_conv_kernel(const ConvArgs a) 
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) *(float4*)(sa + ((tid >> 3) + 32 * i) * CV_LDS + ch4 * 4) = ra[i];
+        if (NB == 0) {
+            if (tid < 32) *(float4*)(sw + (tid >> 3) * CV_LDS + ch4 * 4) = rw[0];
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NB; ++i) *(float4*)(sw + ((tid >> 3) + 32 * i) * CV_LDS + ch4 * 4) = rw[i];
     };
 
-    f32x16_t acc[NB];
+    f32x16_t acc[NW];
 #pragma unroll
-    for (int i = 0; i < NB; ++i)
+    for (int i = 0; i < NW; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    f32x4_t acc4 = {0.f, 0.f, 0.f, 0.f};              // NB = 0: couts 0..3 of the lane's voxel, this lane half's share of k
 
+    // K slice of this workgroup (ksplit: 1x1x1 GEMMs with few output tiles — P.V of the attention block): channel chunks
+    // [kc0, kc1) of the single tap
+    int kc0 = 0, kc1 = nchunk;
+    if (a.ksplit > 1) {
+        kc0 = (int)((int64_t)nchunk * blockIdx.z / a.ksplit);
+        kc1 = (int)((int64_t)nchunk * (blockIdx.z + 1) / a.ksplit);
+        ld_cc = kc0;
+        if (kc0) tap_pointers();                                      // load_chunk() computes them for chunk 0 of a tap only
+    }
     load_chunk();
-    store_chunk(0);
+    store_chunk(kc0 & 1);
     __syncthreads();
-    for (int kc = 0; kc < nchunk; ++kc) {
-        if (kc + 1 < nchunk) load_chunk();
+    for (int kc = kc0; kc < kc1; ++kc) {
+        if (kc + 1 < kc1) load_chunk();
         // pin the order loads | MFMAs | LDS stores: without the fences hipcc moves the ds_writes of the staged rows up in
         // front of the MFMA block (it can prove they touch the other buffer) and then waits for the loads right away
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         const float* sa = smem + (kc & 1) * (CV_BM + BN) * CV_LDS + (wave * 32 + l31) * CV_LDS + g * 4;
         const float* sw = smem + (kc & 1) * (CV_BM + BN) * CV_LDS + CV_BM * CV_LDS + l31 * CV_LDS + g * 4;
-        if (FAST) {
+        if (NB == 0) {
+            // A = weights: lane l holds w[cout l & 3][k]; B = voxels: lane l holds x[voxel l31][k]; block l >> 2 pairs them
+            const float* s4 = smem + (kc & 1) * (CV_BM + BN) * CV_LDS + CV_BM * CV_LDS + (lane & 3) * CV_LDS + g * 4;
+#pragma unroll
+            for (int k8 = 0; k8 < 4; ++k8) {
+                const float4 xa = *(const float4*)(sa + k8 * 8);
+                const float4 wa = *(const float4*)(s4 + k8 * 8);
+                acc4 = __builtin_amdgcn_mfma_f32_4x4x1f32(wa.x, xa.x, acc4, 0, 0, 0);
+                acc4 = __builtin_amdgcn_mfma_f32_4x4x1f32(wa.y, xa.y, acc4, 0, 0, 0);
+                acc4 = __builtin_amdgcn_mfma_f32_4x4x1f32(wa.z, xa.z, acc4, 0, 0, 0);
+                acc4 = __builtin_amdgcn_mfma_f32_4x4x1f32(wa.w, xa.w, acc4, 0, 0, 0);
+            }
+        } else if (FAST) {
             // lane (l31, g): row l31, k = 16 s + 8 g .. + 7 of k-step s: 16 bytes at byte 32 s + 16 g of the hi plane (lo: + 64)
             const char* xa = (const char*)(sa - g * 4) + g * 16;
             const char* wa = (const char*)(sw - g * 4) + g * 16;
@@ -293,7 +327,7 @@ __global__ __launch_bounds__(CV_THREADS) void vae_conv_kernel(const ConvArgs a) 
         for (int k8 = 0; k8 < 4; ++k8) {
             const float4 xa = *(const float4*)(sa + k8 * 8);
             const float xv[4] = {xa.x, xa.y, xa.z, xa.w};
-            float4 wv4[NB];
+            float4 wv4[NW];
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) wv4[nb] = *(const float4*)(sw + nb * 32 * CV_LDS + k8 * 8);
 #pragma unroll
@@ -307,7 +341,7 @@ __global__ __launch_bounds__(CV_THREADS) void vae_conv_kernel(const ConvArgs a) 
         }
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        if (kc + 1 < nchunk) store_chunk((kc + 1) & 1);
+        if (kc + 1 < kc1) store_chunk((kc + 1) & 1);
         __syncthreads();
     }
 
@@ -320,7 +354,43 @@ __global__ __launch_bounds__(CV_THREADS) void vae_conv_kernel(const ConvArgs a) 
         const int y = rem / a.W, x = rem - y * a.W;
         m_out = ((int64_t)t * 2 * a.H + 2 * y + (ph >> 1)) * (2 * a.W) + 2 * x + (ph & 1);
     }
-    cv_epilogue<NB, 1>(a, acc, m_in, m_out, n0, g);
+    if (NB == 0) {
+        // the two lane halves hold the even / odd float4 of every 8 channels of the same voxel: add them, then lanes 0-31
+        // apply (acc * scale + bias) + residual as cv_epilogue does and store the row's <= 4 couts
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc4[i] += __shfl_xor(acc4[i], 32, 64);
+        if (g == 0 && m_in < a.M) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < a.Cout) {
+                    float v = acc4[i] * a.out_scale + (a.bias ? a.bias[i] : 0.f);
+                    if (a.residual) v += a.residual[m_out * a.ldo + i];
+                    a.out[m_out * a.ldo + i] = v;
+                }
+        }
+        return;
+    }
+    if (a.ksplit > 1) {     // raw partial sums of this K slice; vae_ksplit_reduce_kernel adds the slices in a fixed order
+        ConvArgs b = a;
+        b.out = a.out + (int64_t)blockIdx.z * a.part_stride;
+        b.bias = nullptr; b.residual = nullptr; b.out_scale = 1.f;
+        cv_epilogue<NW, 1>(b, acc, m_in, m_out, n0, g);
+        return;
+    }
+    cv_epilogue<NW, 1>(a, acc, m_in, m_out, n0, g);
+}
+
+// out[m][n] = (sum over the K slices z of part[z][m][n]) (fixed order: deterministic), rows of n floats, n % 4 == 0
+__global__ __launch_bounds__(256) void vae_ksplit_reduce_kernel(const float* __restrict__ part, int64_t part_stride, int Z,
+                                                                float* __restrict__ out, int64_t total4) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 s4 = ((const float4*)part)[i];
+        for (int z = 1; z < Z; ++z) {
+            const float4 p = ((const float4*)(part + (int64_t)z * part_stride))[i];
+            s4.x += p.x; s4.y += p.y; s4.z += p.z; s4.w += p.w;
+        }
+        ((float4*)out)[i] = s4;
+    }
 }
 
 // mode: MG_VAE_EXACT = fp32 MFMA (the reference's arithmetic), MG_VAE_BF16X3 = split-bf16 x 3 (opt-in fast mode) — an
@@ -332,12 +402,18 @@ static int launch_conv(const ConvArgs& a, hipStream_t st, int mode) {
     const int64_t tiles_m = (a.M + CV_BM - 1) / CV_BM;
     if (tiles_m > 0x7fffffffLL) return MG_ERR_SHAPE;
     int nb;
-    if (a.Cout <= 32) nb = 1;
+    if (a.Cout <= 4 && !a.phases && a.ksplit <= 1) nb = 0;        // the decoder head (96 -> 3): v_mfma_f32_4x4x1, exact in either mode
+    else if (a.Cout <= 32) nb = 1;
     else if (a.Cout % 128 == 0) nb = 4;
     else if (a.Cout % 96 == 0) nb = 3;
     else nb = 4;
-    const int bn = 32 * nb;
-    const dim3 grid((unsigned)tiles_m, (unsigned)((a.Cout + bn - 1) / bn), a.phases ? 4u : 1u), block(CV_THREADS);
+    const int bn = nb ? 32 * nb : 4;
+    if (a.ksplit > 1 && (a.phases || a.kt * a.kh * a.kw != 1)) return MG_ERR_ARG;
+    const dim3 grid((unsigned)tiles_m, (unsigned)((a.Cout + bn - 1) / bn), a.phases ? 4u : a.ksplit > 1 ? (unsigned)a.ksplit : 1u), block(CV_THREADS);
+    if (nb == 0) {
+        hipLaunchKernelGGL((vae_conv_kernel<0, false>), grid, block, 0, st, a);
+        return mg_check_launch();
+    }
     if (mode == MG_VAE_BF16X3) {
         if (nb == 1) hipLaunchKernelGGL((vae_conv_kernel<1, true>), grid, block, 0, st, a);
         else if (nb == 3) hipLaunchKernelGGL((vae_conv_kernel<3, true>), grid, block, 0, st, a);
@@ -510,10 +586,22 @@ __global__ void transpose_f32_kernel(const float* __restrict__ in, int64_t ldin,
 // workspace is (QB + C) * L floats instead of the full L x L matrix (2.5 GB at 1920x832).  Same arithmetic per row.
 #define VAE_ATTN_QB 2048
 
+// P.V of a query block is a GEMM with M = QB rows, N = C and K = L: 16 x 3 output tiles for 256 CUs.  Its K range is cut
+// into VAE_ATTN_KSPLIT slices (one more grid dimension: 384 workgroups), each writes raw partial sums and a small kernel
+// adds the slices in a fixed order — deterministic, unlike atomics.  (Measured before: 116 ms per 4-frame chunk at
+// 104 x 240 for the attention block = 3.7x the cost per MAC of the 3x3x3 convolutions, most of it this launch at 19 %
+// of the CUs; profiles/r04a_vae_stages.txt.)
+#define VAE_ATTN_KSPLIT 8
+
+static int64_t vae_attn_ksplit(int64_t nq, int C) {
+    const int64_t tiles = ((nq + CV_BM - 1) / CV_BM) * ((C + 127) / 128);
+    return tiles >= 256 ? 1 : VAE_ATTN_KSPLIT;
+}
+
 extern "C" int64_t mg_vae_attn_workspace_floats(int64_t L, int C) {
     const int64_t Lp = (L + 3) & ~(int64_t)3;
     const int64_t qb = L < VAE_ATTN_QB ? L : VAE_ATTN_QB;
-    return (qb + C) * Lp;
+    return (qb + C) * Lp + VAE_ATTN_KSPLIT * qb * C;
 }
 
 extern "C" int mg_vae_attn_f32(const float* qkv, float* out, int frames, int64_t L, int C, float* workspace,
@@ -526,6 +614,7 @@ extern "C" int mg_vae_attn_f32(const float* qkv, float* out, int frames, int64_t
     const int64_t QB = L < VAE_ATTN_QB ? L : VAE_ATTN_QB;
     float* S = workspace;                 // [QB][Lp]
     float* vT = workspace + QB * Lp;      // [C][Lp]
+    float* part = vT + (int64_t)C * Lp;   // [KSPLIT][QB][C] partial sums of P.V
     for (int f = 0; f < frames; ++f) {
         const float* base = qkv + (int64_t)f * L * 3 * C;
         hipLaunchKernelGGL(transpose_f32_kernel, dim3((unsigned)((Lp + 31) / 32), (unsigned)((C + 31) / 32)),
@@ -542,10 +631,21 @@ extern "C" int mg_vae_attn_f32(const float* qkv, float* out, int frames, int64_t
             if (rc) return rc;
             hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)nq), dim3(256), 0, st, S, L, Lp);
             // out[nq][C] = P[nq][Lp] . vT[C][Lp]^T   (padding columns are zero on both sides)
-            a.x = S; a.ldx = Lp; a.Cin = (int)Lp; a.w = vT; a.ldw = Lp; a.Cout = C; a.out = out + ((int64_t)f * L + q0) * C;
+            float* dst = out + ((int64_t)f * L + q0) * C;
+            a.x = S; a.ldx = Lp; a.Cin = (int)Lp; a.w = vT; a.ldw = Lp; a.Cout = C; a.out = dst;
             a.ldo = C; a.out_scale = 1.f;
+            const int Z = (int)vae_attn_ksplit(nq, C);
+            if (Z > 1) {
+                a.out = part; a.ksplit = Z; a.part_stride = nq * C;
+            }
             rc = launch_conv(a, st, MG_VAE_EXACT);
             if (rc) return rc;
+            if (Z > 1) {
+                const int64_t total4 = nq * C / 4;
+                hipLaunchKernelGGL(vae_ksplit_reduce_kernel, dim3((unsigned)((total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048)), dim3(256), 0,
+                                   st, part, nq * C, Z, dst, total4);
+                a.ksplit = 0; a.part_stride = 0;
+            }
         }
     }
     return mg_check_launch();

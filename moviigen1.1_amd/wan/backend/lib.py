@@ -21,7 +21,7 @@ SIGNATURES = {
     'mg_gemm_bf16': [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_vp],
     'mg_attn_fwd_bf16_hd128': [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_f32, c_vp],
     'mg_attn_fwd_bf16_hd128_lse': [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_f32, c_vp],
-    'mg_attn_fwd_bf16_hd128_prescaled': [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_vp],
+    'mg_attn_fwd_bf16_hd128_prescaled': [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_int, c_vp],
     'mg_attn_merge_f32': [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_vp],
     'mg_attn_fwd_bf16_generic': [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_int, c_int,
                                  c_f32, c_vp],

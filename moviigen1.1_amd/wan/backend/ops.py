@@ -84,16 +84,17 @@ def gemm(a, w, bias, epilogue, out, gate=None):
     return out
 
 
-def attention_hd128(q, kp, vp, out, lk, heads, scale, prescaled=False):
+def attention_hd128(q, kp, vp, out, lk, heads, scale, prescaled=False, reserve_cus=0):
     """q [Lq, >=heads*128] bf16; kp/vp from pack_kv for the same lk keys; out [Lq, >=heads*128].
-    prescaled: q was produced with rmsnorm_rope(out_scale=scale * ATTN_LOG2E) — `scale` is then only documentation."""
+    prescaled: q was produced with rmsnorm_rope(out_scale=scale * ATTN_LOG2E) — `scale` is then only documentation.
+    reserve_cus (prescaled entry): CUs the persistent grid leaves free for a kernel on another stream (the exchange)."""
     _chk(q, torch.bfloat16, 'q'); _chk(kp, torch.bfloat16, 'kp'); _chk(vp, torch.bfloat16, 'vp')
     _chk(out, torch.bfloat16, 'out')
     if min(kp.numel(), vp.numel()) < packed_kv_numel(int(lk), int(heads)):
         raise lib.MoviigenHipError('packed K/V buffers too small for lk keys')
     if prescaled:
         lib.call('mg_attn_fwd_bf16_hd128_prescaled', _p(q), q.stride(0), _p(kp), _p(vp), _p(out), out.stride(0), None,
-                 q.shape[0], int(lk), int(heads), _st())
+                 q.shape[0], int(lk), int(heads), int(reserve_cus), _st())
     else:
         lib.call('mg_attn_fwd_bf16_hd128', _p(q), q.stride(0), _p(kp), _p(vp), _p(out), out.stride(0), q.shape[0],
                  int(lk), int(heads), float(scale), _st())
@@ -337,7 +338,7 @@ def attention_hd128_lse(q, kp, vp, out, lse, lk, heads, scale, prescaled=False):
         raise lib.MoviigenHipError('lse must be a contiguous [heads, Lq] fp32 tensor')
     if prescaled:
         lib.call('mg_attn_fwd_bf16_hd128_prescaled', _p(q), q.stride(0), _p(kp), _p(vp), _p(out), out.stride(0), _p(lse),
-                 q.shape[0], int(lk), int(heads), _st())
+                 q.shape[0], int(lk), int(heads), 0, _st())
     else:
         lib.call('mg_attn_fwd_bf16_hd128_lse', _p(q), q.stride(0), _p(kp), _p(vp), _p(out), out.stride(0), _p(lse),
                  q.shape[0], int(lk), int(heads), float(scale), _st())

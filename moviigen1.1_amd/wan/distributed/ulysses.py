@@ -101,6 +101,10 @@ class HeadExchange:
         if peer_copy.enabled() and self.recv[0].is_cuda and group is not None:
             self.peer = peer_copy.open_windows(group, self.recv + self.orecv)      # None (logged) when IPC mapping is unavailable
         self.comm = torch.cuda.Stream(device=device)
+        # CUs the attention launches of this layer leave free while exchanges are in flight (ops.attention_hd128
+        # reserve_cus; DESIGN.md 4: the collective transports are kernels and the attention grid is persistent, one
+        # workgroup per CU with the whole register file).  The copy-engine transport needs none.
+        self.reserve_cus = 0 if self.peer is not None or len(self.groups) < 2 else int(os.environ.get('MOVIIGEN_SP_RESERVE_CUS', '8'))
         ev = lambda: [torch.cuda.Event() for _ in self.groups]  # noqa: E731
         self.ev_pack, self.ev_recv, self.ev_attn, self.ev_o = ev(), ev(), ev(), ev()
 

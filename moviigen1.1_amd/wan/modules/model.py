@@ -507,7 +507,9 @@ class WanModel(nn.Module):
             elif hd == 128:
                 kv = min(kg.shape[0], self._kv_valid)       # keys past the video's tokens are padding (k_lens)
                 ops.pack_kv(kg[:kv], vg[:kv], heads, ws['kp'], ws['vp'])
-                ops.attention_hd128(qg, ws['kp'], ws['vp'], ag, kv, heads, scale, prescaled=True)
+                # while an exchange is in flight the persistent attention grid leaves `reserve_cus` CUs to RCCL's kernels
+                ops.attention_hd128(qg, ws['kp'], ws['vp'], ag, kv, heads, scale, prescaled=True,
+                                    reserve_cus=ws['xchg'].reserve_cus if 'xchg' in ws else 0)
             else:
                 ops.attention_generic(qg, kg, vg, ag, min(kg.shape[0], self._kv_valid), heads, hd, scale)
 

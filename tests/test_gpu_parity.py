@@ -413,7 +413,9 @@ def test_operator_seam_flash_attention(dev, cfg):
     module-level name for every self-attention (:146-151) and cross-attention (:176), so a replacement is installed by
     assigning `wan.modules.model.flash_attention`.  The same assignment here must be honoured: the bound function is
     called with the reference's arguments (q / k roped and UNSCALED, [1, L, N, hd]; k_lens; window_size) 2 x layers
-    times per forward, its result is what the block uses, and un-binding restores the fused path bit for bit."""
+    times per forward, its result is what the block uses, and un-binding restores the fused path bit for bit.  (One
+    difference in the call: the engine never materialises the rows that pad a video to seq_len — the reference carries
+    them through every block and drops them in unpatchify — so q / k / v hold the L valid tokens, k_lens == L.)"""
     import wan
     import wan.modules.model as wm
     from wan.modules.attention import flash_attention as engine_fa
@@ -434,8 +436,8 @@ def test_operator_seam_flash_attention(dev, cfg):
     try:
         out = m([lat], t=t, context=[ctx], seq_len=60)[0].clone()
         assert len(calls) == 2 * cfg['num_layers']
-        assert calls[0] == ((1, 60, N, hd), (1, 60, N, hd), (1, 60, N, hd), 48, (-1, -1))                # self-attention
-        assert calls[1] == ((1, 60, N, hd), (1, cfg['text_len'], N, hd), (1, cfg['text_len'], N, hd), None, (-1, -1))   # cross
+        assert calls[0] == ((1, 48, N, hd), (1, 48, N, hd), (1, 48, N, hd), 48, (-1, -1))                # self-attention
+        assert calls[1] == ((1, 48, N, hd), (1, cfg['text_len'], N, hd), (1, cfg['text_len'], N, hd), None, (-1, -1))   # cross
         # same operator underneath: equal up to where q's scale is folded in (before / after its rounding to bf16)
         assert rel_l2(out, base) < 1e-2
         # the function's result really is what the block uses
@@ -888,7 +890,7 @@ def test_vae_fast_mode(dev, golden):
             ops.vae_conv(x, w, b, o, 3, 3, 3, cache=cache, residual=res, mode=mode)
             outs.append(o)
         assert torch.isfinite(outs[1]).all().item()
-        assert not torch.equal(outs[0], outs[1])                    # the fast kernel really ran
+        assert torch.equal(outs[0], outs[1]) == (cout <= 4)         # the fast kernel really ran (Cout <= 4 — the head — is exact in either mode)
         assert ((outs[0] - outs[1]).abs().max() / outs[0].abs().max()).item() < 1e-4
     x = torch.randn(2, 10, 14, 192, device=dev, generator=gen)
     wp = ops.vae_upconv_fold_weights(torch.randn(96, 1, 3, 3, 192, device=dev, generator=gen) / math.sqrt(9 * 192))

@@ -32,20 +32,70 @@ def run():
     torch.cuda.set_device(0)
     dev = torch.device('cuda:0')
     dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
-    cfg = dict(model_type='t2v', patch_size=(1, 2, 2), text_len=64, in_dim=16, dim=1024, ffn_dim=2048, freq_dim=64,
-               text_dim=128, out_dim=16, num_heads=8, num_layers=2, eps=1e-6)
+    shape = os.environ.get('SP_TRACE_SHAPE', 'small')
+    if shape == 'cfg2':
+        # the per-rank group size of BASELINE configs[2] (1920x832x81f, Ulysses 8): L = 131 040 tokens x 5 local heads, ONE
+        # head per pipeline group — 5.8 ms of attention per group; the loop-back exchange moves what 8 ranks together put
+        # into this rank's receive buffer (131 040 x 384 x 2 B = 100 MB; per peer link it is 12.6 MB)
+        os.environ['MOVIIGEN_SP_GROUPS'] = '5'
+        cfg = dict(model_type='t2v', patch_size=(1, 2, 2), text_len=64, in_dim=16, dim=640, ffn_dim=1280, freq_dim=64,
+                   text_dim=128, out_dim=16, num_heads=5, num_layers=2, eps=1e-6)
+        lat_shape, L = (16, 21, 104, 240), 131040
+    elif shape == 'fsdp':
+        # block-shard prefetch: the 703 MB all-gather of a 14B-width block (loop-back on one rank) under the compute of
+        # the previous block at the per-rank token count of configs[3] (L/4 = 41 580 rows)
+        cfg = dict(model_type='t2v', patch_size=(1, 2, 2), text_len=512, in_dim=16, dim=5120, ffn_dim=13824, freq_dim=256,
+                   text_dim=4096, out_dim=16, num_heads=40, num_layers=4, eps=1e-6)
+        lat_shape, L = (16, 21, 66, 120), 41580
+    else:
+        cfg = dict(model_type='t2v', patch_size=(1, 2, 2), text_len=64, in_dim=16, dim=1024, ffn_dim=2048, freq_dim=64,
+                   text_dim=128, out_dim=16, num_heads=8, num_layers=2, eps=1e-6)
+        lat_shape, L = (16, 16, 64, 64), 16384             # grid (16, 32, 32) = 16 384 tokens
     m = wan.modules.WanModel(**cfg, device=dev).init_weights(0)
-    lat = W.randn((16, 16, 64, 64), 3).to(dev)             # grid (16, 32, 32) = 16 384 tokens
-    ctx = W.randn((20, 128), 4).to(dev)
+    lat = W.randn(lat_shape, 3).to(dev)
+    ctx = W.randn((20, cfg['text_dim']), 4).to(dev)
     t = torch.tensor([500.0], device=dev)
-    ref = m([lat], t=t, context=[ctx], seq_len=16384)[0].clone()
+    ref = m([lat], t=t, context=[ctx], seq_len=L)[0].clone()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    m([lat], t=t, context=[ctx], seq_len=L)
+    b.record()
+    torch.cuda.synchronize()
+    plain_ms = a.elapsed_time(b)
+    if shape == 'fsdp':
+        from wan.distributed.collectives import trace_summary
+        from wan.distributed.fsdp import BlockShards, shard_model
+        shard_model(m, device_id=0)
+        for _ in range(2):
+            got = m([lat], t=t, context=[ctx], seq_len=L)[0]
+        BlockShards.trace = []
+        a.record()
+        got = m([lat], t=t, context=[ctx], seq_len=L)[0]
+        b.record()
+        torch.cuda.synchronize()
+        tr = trace_summary(BlockShards.trace)
+        BlockShards.trace = None
+        assert torch.equal(got, ref)
+        print(f'FSDP_OVERLAP_RUN_OK forward_ms unsharded {plain_ms:.2f} sharded(prefetch) {a.elapsed_time(b):.2f} gathers {tr["collectives"]} '
+              f'gather_ms {tr["comm_ms"]:.2f} exposed_ms {tr["exposed_ms"]:.2f} hidden_frac {tr["hidden_frac"]}', flush=True)
+        dist.destroy_process_group()
+        return
     enable_sequence_parallel(m)
     m.sp_force = True
-    for _ in range(3):
-        got = m([lat], t=t, context=[ctx], seq_len=16384)[0]
+    from wan.distributed.ulysses import HeadExchange
+    for _ in range(2):
+        got = m([lat], t=t, context=[ctx], seq_len=L)[0]
+    HeadExchange.trace = []
+    a.record()
+    got = m([lat], t=t, context=[ctx], seq_len=L)[0]
+    b.record()
     torch.cuda.synchronize()
+    ov = HeadExchange.overlap_summary()
+    HeadExchange.trace = None
     assert torch.equal(got, ref)
-    print('SP_OVERLAP_RUN_OK groups', m._ws[next(iter(m._ws))]['xchg'].groups, flush=True)
+    x = m._ws[next(iter(m._ws))]['xchg']
+    print(f'SP_OVERLAP_RUN_OK shape {shape} groups {x.groups} reserve_cus {x.reserve_cus} forward_ms plain {plain_ms:.2f} exchanged {a.elapsed_time(b):.2f} '
+          f'exchange_ms {ov["exchange_ms"]:.2f} exposed_ms {ov["exposed_ms"]:.2f} hidden_frac {ov["hidden_frac"]}', flush=True)
     dist.destroy_process_group()
 
 
@@ -73,8 +123,8 @@ def analyse(d, out=None):
     c_tot = sum(e - s for s, e, _ in comm)
     c_ov = overlap([(s, e) for s, e, _ in comm])
     label = os.environ.get('SP_TRACE_LABEL', 'default')
-    lines = [f'# tools/sp_overlap_trace.py [{label}]: rocprofv3 --kernel-trace of the pipelined Ulysses exchange, backend nccl (RCCL), 1 rank, ' + os.environ.get('MOVIIGEN_SP_GROUPS', '4') + ' head groups, transport ' + (os.environ.get('MOVIIGEN_SP_TRANSPORT') or 'torch') + ',',
-             f'attention kernels          : n={len(attn)} total_us={sum(b - a for a, b in attn) / 1e3:.1f}',
+    lines = [f'# tools/sp_overlap_trace.py [{label}]: rocprofv3 --kernel-trace of the pipelined Ulysses exchange, backend nccl (RCCL), 1 rank, shape ' + os.environ.get('SP_TRACE_SHAPE', 'small') + ', transport ' + (os.environ.get('MOVIIGEN_SP_TRANSPORT') or 'torch') + ', reserve_cus ' + os.environ.get('MOVIIGEN_SP_RESERVE_CUS', 'default') + ',',
+             f'attention kernels          : n={len(attn)} total_us={sum(b - a for a, b in attn) / 1e3:.1f} longest_us={max([b - a for a, b in attn] or [0]) / 1e3:.1f}',
              f'RCCL kernels (all-to-all)  : n={len(comm)} total_us={c_tot / 1e3:.1f}  names={sorted({n.split("(")[0][:50] for _, _, n in comm})}',
              f'  of which UNDER attention : {c_ov / 1e3:.1f} us = {100.0 * c_ov / max(c_tot, 1):.1f} % of the RCCL kernel time',
              f'pack / unpack kernels      : n={len(pack)} total_us={sum(b - a for a, b in pack) / 1e3:.1f}',
