@@ -102,9 +102,12 @@ class HeadExchange:
             self.peer = peer_copy.open_windows(group, self.recv + self.orecv)      # None (logged) when IPC mapping is unavailable
         self.comm = torch.cuda.Stream(device=device)
         # CUs the attention launches of this layer leave free while exchanges are in flight (ops.attention_hd128
-        # reserve_cus; DESIGN.md 4: the collective transports are kernels and the attention grid is persistent, one
-        # workgroup per CU with the whole register file).  The copy-engine transport needs none.
-        self.reserve_cus = 0 if self.peer is not None or len(self.groups) < 2 else int(os.environ.get('MOVIIGEN_SP_RESERVE_CUS', '8'))
+        # reserve_cus): the collective transports are kernels and the attention grid is persistent, one workgroup per CU
+        # with the whole register file, so an RCCL kernel only runs once an attention launch has ended.  Measured at the
+        # configs[2] group size (profiles/r04b_sp_overlap.txt): leaving 8 CUs free costs MORE than the exposed
+        # exchange it could hide (512 query blocks of a one-head group on 248 instead of 256 workgroups = three rounds
+        # instead of two: +28 % attention time) — the default is 0; the copy-engine transport needs none either way.
+        self.reserve_cus = 0 if self.peer is not None or len(self.groups) < 2 else int(os.environ.get('MOVIIGEN_SP_RESERVE_CUS', '0'))
         ev = lambda: [torch.cuda.Event() for _ in self.groups]  # noqa: E731
         self.ev_pack, self.ev_recv, self.ev_attn, self.ev_o = ev(), ev(), ev(), ev()
 

@@ -357,7 +357,7 @@ class WanVAE_:
 #   up   = Resample stages (time_conv 3x1x1 + the four 2x2 phase convs + interleave),
 #   attn = the per-frame attention block (qkv / proj 1x1 convs + score blocks of 2048 rows + row softmax),
 #   head = RMS_norm + SiLU + the 96 -> 3 convolution (vae_conv_kernel<1>).
-REL_MS_PER_MAC = {'wide': 1.0, 'narrow': 1.0, 'up': 1.0, 'attn': 1.0, 'head': 1.0}
+REL_MS_PER_MAC = {'wide': 1.0, 'narrow': 1.06, 'up': 1.08, 'attn': 1.5, 'head': 11.7}
 
 
 def pipeline_makespan(seg_ms_first, seg_ms_steady, n_chunks, xfer_ms=None):

@@ -572,7 +572,7 @@ def test_vae_attention_query_blocks(dev, L, C):
     qkv = torch.randn(frames, L, 3 * C, device=dev, generator=gen)
     out = torch.empty(frames, L, C, device=dev)
     ws = torch.empty(ops.vae_attn_workspace_floats(L, C), device=dev)
-    assert ws.numel() <= (2048 + C) * (L + 3)
+    assert ws.numel() <= (2048 + C) * (L + 3) + 8 * 2048 * C       # score block + V^T + the split-K partial sums of P.V
     ops.vae_attn(qkv, out, ws)
     q, k, v = qkv.double().split(C, dim=-1)
     ref = torch.softmax(q @ k.transpose(1, 2) / math.sqrt(C), -1) @ v
@@ -1279,14 +1279,14 @@ def test_attention_lse_and_merge(dev):
 
 
 @pytest.mark.parametrize('world,extra,plain', [(2, [], False), (4, [], True), (2, ['--no-cfg-parallel'], True),
-                                               (4, ['--dit-fsdp', '--vae-parallel', '--transport', 'peer_copy'], False)],
+                                               (4, ['--dit-fsdp', '--vae-parallel', '--transport', 'peer_copy', '--layers', '3'], False)],
                          ids=['cfg2_torchrun', 'cfg2_sp2_plain', 'sp2_plain', 'configs3_form_cfg2_sp2_fsdp4_vaepipe_peercopy'])
 def test_bench_multirank_code_path(world, extra, plain):
     """bench.py's N > 1 branches (CFG-parallel halves x Ulysses, or Ulysses over all ranks; block-sharded weights,
     pipelined VAE tail, exchange transport) on one GPU through gloo, tiny workload: must print ONE JSON line with the
     contract keys.  plain: `python bench.py --gpus N` WITHOUT torch.distributed.run — bench.py launches its own ranks;
     else the driver's torchrun form.  The last case is the command form of BASELINE configs[3] (`--gpus 8 --dit-fsdp` prints
-    `cfg2 x ulysses_sp4 x fsdp8`) at 4 ranks."""
+    `cfg2 x ulysses_sp4 x fsdp8`) at 4 ranks, with 3 layers so that the two gather buffers really rotate."""
     import json
     import os
     import subprocess
