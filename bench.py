@@ -181,6 +181,45 @@ def cpu_baseline(L_step, lat_shape):
                       f'configs[0] (2-layer dim-128 DiT, 2 UniPC steps, CFG) in full: {t_cfg0:.3f}s (best of 3)'}
 
 
+def measure_attention_traffic(L, heads, timeout=240):
+    """HBM-side traffic of ONE launch of the dominant kernel, measured NOW on this box: two separate `rocprofv3 --pmc`
+    passes (FETCH_SIZE, then WRITE_SIZE — they do not fit one pass; --kernel-trace only, as the guide's HBM section
+    prescribes) over `mg_selftest attnpmc L heads` = two launches of mg_attn_fwd_bf16_hd128_prescaled at the workload's
+    launch shape.  FETCH_SIZE is doubled (gfx950 reports half the bytes of a wide coalesced read stream,
+    MI355X_MICROARCH.md), WRITE_SIZE taken as is; both are KiB.  -> (dict, None) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, 'moviigen1.1_amd', 'lib', 'mg_selftest')
+    prof = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if not os.path.exists(exe) or not os.path.exists(prof):
+        return None, 'mg_selftest or rocprofv3 not found'
+    kib = {}
+    for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
+        d = tempfile.mkdtemp(prefix='mg_pmc_', dir='/tmp')
+        try:
+            r = subprocess.run([prof, '--pmc', ctr, '--kernel-trace', '--output-format', 'csv', '-d', d, '-o', 'p', '--', exe, 'attnpmc',
+                                str(L), str(heads)], cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'), capture_output=True, text=True,
+                               timeout=timeout)
+            vals = []
+            for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if 'attn_hd128_m16_kernel' in row['Kernel_Name'] and row.get('Counter_Name', ctr) == ctr:
+                        vals.append(float(row['Counter_Value']))
+            if r.returncode != 0 or not vals:
+                return None, f'{ctr} pass failed (rc {r.returncode}, {len(vals)} dispatches): {(r.stdout + r.stderr)[-300:]}'
+            kib[ctr] = (sum(vals) / len(vals), len(vals))
+        except (subprocess.TimeoutExpired, OSError) as e:
+            return None, f'{ctr} pass: {type(e).__name__}'
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return {'traffic_bytes_per_launch': 2 * kib['FETCH_SIZE'][0] * 1024 + kib['WRITE_SIZE'][0] * 1024,
+            'fetch_size_kib_raw': kib['FETCH_SIZE'][0], 'write_size_kib_raw': kib['WRITE_SIZE'][0],
+            'dispatches': [kib['FETCH_SIZE'][1], kib['WRITE_SIZE'][1]]}, None
+
+
 def launch_command(n, argv, port=None):
     """the torch.distributed.run command line `python bench.py --gpus n ...` re-executes itself under when it is
     started without WORLD_SIZE (one rank per GPU of this node, rendezvous on 127.0.0.1)."""
@@ -214,6 +253,9 @@ def main():
     ap.add_argument('--transport', default=None, choices=['torch', 'rccl_direct', 'peer_copy'],
                     help='N > 1: transport of the Ulysses exchange — torch.distributed nccl (default), the C-ABI collectives on the '
                          "library's own RCCL communicator, or one-sided peer copies on the copy engines")
+    ap.add_argument('--no-pmc', action='store_true',
+                    help="N = 1: skip the two rocprofv3 --pmc passes that measure the dominant kernel's HBM traffic after the timed "
+                         'region (roofline.traffic is then read from the newest committed summary and labelled so)')
     ap.add_argument('--layers', type=int, default=None, help='debug only: fewer layers (marks the line invalid)')
     args = ap.parse_args()
     if args.transport is not None:        # read by wan.distributed at exchange-construction time; inherited by self-launched ranks
@@ -454,9 +496,20 @@ def main():
             line['vae_decode'] = {'seconds': vae_s, 'latent': list(lat_shape), 'tflops_fp32': fx / vae_s / 1e12,
                                   'fp32_mfma_peak_tflops': PEAK_F32_MFMA / 1e12, 'frac': fx / vae_s / PEAK_F32_MFMA,
                                   'algorithmic_tflop': fv / 1e12, 'executed_tflop': fx / 1e12}
-        # HBM-side traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this same
-        # command (tools/round_end_gpu.sh); the newest committed summary FOR THIS WORKLOAD is reported, never a guess
-        if world == 1 and not args.layers:
+        # HBM-side traffic of the dominant kernel: measured HERE, after the timed region, by two rocprofv3 --pmc passes
+        # over the same launch shape (measure_attention_traffic); only when that is impossible (--no-pmc, no rocprofv3)
+        # the newest committed summary for this workload is reported instead, and labelled as such — never a guess
+        live = None
+        if world == 1 and not args.layers and not args.no_pmc and args.workload != 'tiny':
+            live, why = measure_attention_traffic(L, cfg['num_heads'])
+            if live is not None:
+                line['roofline']['traffic'] = live['traffic_bytes_per_launch']
+                line['roofline']['traffic_unit'] = ('bytes/launch, measured in this run: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + --pmc WRITE_SIZE, '
+                                                    f'two passes over mg_selftest attnpmc {L} {cfg["num_heads"]} ({live["dispatches"]} dispatches)')
+                line['roofline']['algorithmic_bytes_per_launch'] = 4 * L * cfg['dim'] * 2
+            else:
+                line['roofline']['traffic_live_failed'] = why
+        if world == 1 and not args.layers and live is None:
             import glob
             found = sorted(glob.glob(os.path.join(ROOT, 'profiles', f'*pmc_traffic_{args.workload}.json')))
             if not found and args.workload == '720p':

@@ -269,6 +269,46 @@ static void test_gemm(int64_t M, int N, int K, int epi, int nsamp, bool timeit) 
     }
 }
 
+// A/B of GEMM schedules on ONE set of operands, interleaved rounds (cdna guide 5.4 rule 24): the operands are generated
+// once per shape, every (round, variant) is timed over 5 launches; results of all variants are compared with the first
+// one's (bit-identical by construction: the schedule never changes the accumulation order).
+static void gemm_ab(int64_t M, int N, int K, int epi, const std::vector<int>& variants, int rounds) {
+    auto A = randbf((size_t)M * K), Wt = randbf((size_t)N * K, 0.05f);
+    auto bias = randf(N), gate = randf(N);
+    const int64_t ldo = (N + 3) / 4 * 4;
+    Dev<uint16_t> dA(A), dW(Wt), ob((size_t)M * ldo);
+    Dev<float> db(bias), dg(gate), of((size_t)M * ldo), of0((size_t)M * ldo);
+    const bool f32out = epi >= 2;
+    if (epi == MG_EPI_GATE_RESID_F32) {     // a bounded residual stream: x accumulates over the timed launches
+        auto r = randf((size_t)M * ldo);
+        CK(hipMemcpy(of0.p, r.data(), r.size() * 4, hipMemcpyHostToDevice));
+    }
+    void* outp = f32out ? (void*)of.p : (void*)ob.p;
+    printf("gemm_ab M=%lld N=%d K=%d epi=%d\n", (long long)M, N, K, epi);
+    std::vector<float> first_f;
+    std::vector<uint16_t> first_b;
+    for (int r = 0; r < rounds; ++r)
+        for (int var : variants) {
+            mg_gemm_set_variant(var);
+            if (f32out) CK(hipMemcpy(of.p, of0.p, of.n * 4, hipMemcpyDeviceToDevice));
+            int rc = mg_gemm_bf16(dA.p, K, dW.p, K, db.p, M, N, K, epi, outp, ldo, dg.p, 0);
+            CK(hipDeviceSynchronize());
+            bool same = rc == 0;
+            if (f32out) {
+                auto h = of.host();
+                if (first_f.empty()) first_f = h; else same = same && !memcmp(h.data(), first_f.data(), h.size() * 4);
+            } else {
+                auto h = ob.host();
+                if (first_b.empty()) first_b = h; else same = same && !memcmp(h.data(), first_b.data(), h.size() * 2);
+            }
+            if (!same) ++n_fail;
+            float ms = time_ms([&] { mg_gemm_bf16(dA.p, K, dW.p, K, db.p, M, N, K, epi, outp, ldo, dg.p, 0); }, 5);
+            printf("  [%s] variant %d round %d: %.3f ms  %.1f TFLOP/s\n", same ? "SAME" : "DIFF", var, r, ms, 2.0 * M * N * K / (ms * 1e-3) / 1e12);
+            fflush(stdout);
+        }
+    mg_gemm_set_variant(0);
+}
+
 static void test_attn(int64_t Lq, int64_t Lk, int heads, int nsamp, bool timeit, int prescaled = 0) {
     const int64_t ld = (int64_t)heads * 128;
     const int64_t npk = (int64_t)heads * ((Lk + 63) / 64) * 8192;
@@ -632,6 +672,21 @@ int main(int argc, char** argv) {
         mg_attn_w64_profile(nullptr);
         return 0;
     }
+    if (argc > 1 && !strcmp(argv[1], "attnpmc")) {  // attnpmc L heads: two launches of the pre-scaled entry on constant operands, nothing
+        // else — what bench.py runs under `rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE` to read the kernel's HBM-side traffic
+        const int64_t L = argc > 2 ? atoll(argv[2]) : 131040;
+        const int heads = argc > 3 ? atoi(argv[3]) : 40;
+        const int64_t ld = (int64_t)heads * 128, npk = (int64_t)heads * ((L + 63) / 64) * 8192;
+        Dev<uint16_t> dq((size_t)L * ld), dkp((size_t)npk), dvp((size_t)npk), dout((size_t)L * ld);
+        CK(hipMemset(dq.p, 0x3c, dq.n * 2));     // bf16 0x3c3c = 0.0115: traffic does not depend on the values
+        CK(hipMemset(dkp.p, 0x3c, dkp.n * 2));
+        CK(hipMemset(dvp.p, 0x3c, dvp.n * 2));
+        int rc = 0;
+        for (int i = 0; i < 2; ++i) rc |= mg_attn_fwd_bf16_hd128_prescaled(dq.p, ld, dkp.p, dvp.p, dout.p, ld, nullptr, L, L, heads, 0, 0);
+        CK(hipDeviceSynchronize());
+        printf("attnpmc L=%lld heads=%d rc=%d\n", (long long)L, heads, rc);
+        return rc ? 1 : 0;
+    }
     if (argc > 1 && !strcmp(argv[1], "attn1")) {  // single big launch set, for rocprofv3 --pmc passes
         mg_attn_set_variant(argc > 2 ? atoi(argv[2]) : 0);
         test_attn(argc > 3 ? atoll(argv[3]) : 75600, argc > 3 ? atoll(argv[3]) : 75600, 8, 8, true, 1);
@@ -645,6 +700,18 @@ int main(int argc, char** argv) {
         test_gemm(Mg, 5120, 5120, 0, 128, true);      // cross-attention q
         test_gemm(Mg, 13824, 5120, 1, 128, true);     // ffn.0 + GELU
         test_gemm(Mg, 5120, 13824, 2, 128, true);     // ffn.2 (+ gate, residual)
+        return n_fail ? 1 : 0;
+    }
+    if (argc > 1 && !strcmp(argv[1], "gemmab")) {   // gemmab M rounds v1 v2 ...: the three residual / one store GEMM of a block, variants alternating
+        const int64_t Mg = argc > 2 ? atoll(argv[2]) : 131040;
+        const int rounds = argc > 3 ? atoi(argv[3]) : 2;
+        std::vector<int> vars;
+        for (int i = 4; i < argc; ++i) vars.push_back(atoi(argv[i]));
+        if (vars.empty()) vars = {80, 81};
+        gemm_ab(Mg, 5120, 5120, 2, vars, rounds);      // self-attention o (+ gate, residual)
+        gemm_ab(Mg, 5120, 13824, 2, vars, rounds);     // ffn.2 (+ gate, residual)
+        gemm_ab(Mg, 5120, 5120, 0, vars, rounds);      // cross-attention q: store epilogue, the variants must tie
+        printf("%s: %d failure(s)\n", n_fail ? "SELFTEST FAILED" : "SELFTEST OK", n_fail);
         return n_fail ? 1 : 0;
     }
     if (argc > 1 && !strcmp(argv[1], "gemmprof")) {  // s_memtime breakdown of the 256x128 GEMM k-loop
