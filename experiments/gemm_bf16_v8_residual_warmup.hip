@@ -1,3 +1,10 @@
+// ARCHIVED EXPERIMENT (round 4, not built into the library): GEMM variant 8 with a residual warm-up — `warm_kt` k-tiles before
+// the end of a tile every wave touches the 128-byte lines of its 128 x 64 fp32 block of x with four LDS-DMA dword loads into a
+// sink, so that the gated-residual epilogue's four read-modify-write round trips hit the L2.  Measured same-box, alternating
+// (profiles/r04c_gemm_residual_warmup.log, M = 131 040): o-proj 1111-1114 TFLOP/s without vs 1070-1078 with (1 / 2 / 3 k-tiles
+// ahead), ffn.2 1219-1226 vs 1199-1207, the store epilogue unchanged (1273-1279): the warm-up costs 1.5-4 % instead of
+// gaining — the epilogue is bound by the CU's 64 B/clk vector-memory path (512 KiB of x in and out per tile), not by the
+// latency of its first loads, and the extra requests compete with the operand stream.
 // bf16 GEMM, variant 8: the 256 x 256 x 64 tile of variant 7 with EIGHT waves in two ping-pong groups — the structure that
 // hides a wave's LDS-DMA issue and fragment reads behind its SIMD partner's MFMAs (cdna guide 5: the 8-phase idea, built
 // here on this library's LDS image and refill protocol).
@@ -34,6 +41,7 @@
 typedef const __attribute__((address_space(1))) void* v8_gptr_t;
 typedef __attribute__((address_space(3))) void* v8_lptr_t;
 MG_DEV void v8_glds16(const void* g, void* l) { __builtin_amdgcn_global_load_lds((v8_gptr_t)g, (v8_lptr_t)l, 16, 0, 0); }
+MG_DEV void v8_glds4(const void* g, void* l) { __builtin_amdgcn_global_load_lds((v8_gptr_t)g, (v8_lptr_t)l, 4, 0, 0); }
 
 template <int OFF>
 MG_DEV void v8_rd(bf16x8_t& dst, unsigned addr) {
@@ -56,9 +64,10 @@ template <int EPI, bool PROF = false>
 __global__ __launch_bounds__(V8_THREADS, 2) void gemm_bf16_v8_kernel(
     const uint16_t* __restrict__ A, int64_t lda, const uint16_t* __restrict__ Wt, int64_t ldw,
     const float* __restrict__ bias, int64_t M, int N, int K, void* __restrict__ out, int64_t ldo,
-    const float* __restrict__ gate, int tiles_m, int tiles_n, int raster, unsigned long long* __restrict__ prof) {
+    const float* __restrict__ gate, int tiles_m, int tiles_n, int raster, int warm_kt, unsigned long long* __restrict__ prof) {
     unsigned long long pt[5] = {0, 0, 0, 0, 0};
     __shared__ __attribute__((aligned(16))) char smem[2 * V8_STAGE];
+    __shared__ __attribute__((aligned(16))) char warm_sink[256];     // where the residual warm-up loads land (never read)
 
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int total = tiles_m * tiles_n;
@@ -171,7 +180,28 @@ __global__ __launch_bounds__(V8_THREADS, 2) void gemm_bf16_v8_kernel(
 #pragma unroll
                     for (int p = 4 * ph; p < 4 * ph + 4; ++p) v8_glds16(gp[p] + koff2, lnext + piece_lds(p));
                 }
-                if (ph == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my pieces of the next k-tile have landed
+                // Gated-residual epilogue: its four read-modify-write round trips of x (one per column group; the 128 arch
+                // VGPRs hold one group's eight quads at a time) run with the matrix pipe idle.  `warm_kt` k-tiles before the
+                // end, right behind this k-tile's last piece, the wave touches every 128-byte line of its 128 x 64 fp32 block
+                // of x — four LDS-DMA dword loads into a sink, no VGPR destination, nothing to keep alive — so the
+                // epilogue's loads find their lines in the L2 instead of starting four HBM round trips.  vmcnt retires
+                // loads in order: in this k-tile phase 3 waits for all but the four youngest (= the pieces).
+                const bool warm_now = EPI == MG_EPI_GATE_RESID_F32 && warm_kt > 0 && kt == nk - warm_kt;
+                if (EPI == MG_EPI_GATE_RESID_F32 && ph == 1 && warm_now) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int id = i * 64 + lane;                       // line (row id >> 1, half id & 1) of the wave's block
+                        int64_t xm = m0 + wm * 128 + (id >> 1);
+                        if (xm > M - 1) xm = M - 1;
+                        int xn = n0 + wn * 64 + (id & 1) * 32;
+                        if (xn > N - 4) xn = N - 4;
+                        v8_glds4((const float*)out + xm * ldo + xn, warm_sink);
+                    }
+                }
+                if (ph == 3) {      // my pieces of the next k-tile have landed
+                    if (warm_now) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // my fragment reads are retired
                 const unsigned long long c1 = PROF ? __builtin_amdgcn_s_memtime() : 0;
                 __builtin_amdgcn_s_barrier();
@@ -206,6 +236,11 @@ __global__ __launch_bounds__(V8_THREADS, 2) void gemm_bf16_v8_kernel(
     }
 }
 
+// k-tiles before the end of a tile at which the gated-residual kernel warms the L2 with its block of x (0 = never);
+// mg_gemm_set_variant(80 + n) selects n for A/B runs (gemm_bf16.hip), 8 = the default below
+static int g_v8_warm_kt = 1;
+void mg_gemm_v8_set_warm(int kt) { g_v8_warm_kt = kt < 0 ? 0 : kt; }
+
 int mg_gemm_v8_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_t ldw, const float* bias, int64_t M,
                       int N, int K, int epilogue, void* out, int64_t ldo, const float* gate, hipStream_t st) {
     int n_cu = mg_cu_count();
@@ -227,12 +262,12 @@ int mg_gemm_v8_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_
     const dim3 grid((unsigned)nwg), block(V8_THREADS);
     if (g_gemm5_prof && epilogue == MG_EPI_BIAS_BF16) {
         hipLaunchKernelGGL((gemm_bf16_v8_kernel<MG_EPI_BIAS_BF16, true>), grid, block, 0, st, A, lda, Wt, ldw, bias, M, N, K,
-                           out, ldo, gate, tiles_m, tiles_n, raster, g_gemm5_prof);
+                           out, ldo, gate, tiles_m, tiles_n, raster, 0, g_gemm5_prof);
         return mg_check_launch();
     }
 #define LAUNCH(E)                                                                                          \
     hipLaunchKernelGGL((gemm_bf16_v8_kernel<E, false>), grid, block, 0, st, A, lda, Wt, ldw, bias, M, N, K, out, ldo, \
-                       gate, tiles_m, tiles_n, raster, nullptr)
+                       gate, tiles_m, tiles_n, raster, (K / V8_BK) > g_v8_warm_kt ? g_v8_warm_kt : 0, nullptr)
     switch (epilogue) {
         case MG_EPI_BIAS_BF16: LAUNCH(MG_EPI_BIAS_BF16); break;
         case MG_EPI_BIAS_GELU_BF16: LAUNCH(MG_EPI_BIAS_GELU_BF16); break;

@@ -150,11 +150,7 @@ int mg_gemm_v2_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_
 unsigned long long* g_gemm5_prof = nullptr;   // debug hook of the 256x256 kernels (variants 5 and 7): 4 waves x {wait+barrier, first half, second half, k-tiles}
 extern "C" void mg_gemm5_debug_profile(unsigned long long* dev_buf) { g_gemm5_prof = dev_buf; }
 static int g_gemm_variant = 0;   // 0 = by shape AND epilogue (below)
-void mg_gemm_v8_set_warm(int kt);
-extern "C" void mg_gemm_set_variant(int v) {      // 80 + n: variant 8 with the residual warm-up n k-tiles before a tile's end (0 = off)
-    g_gemm_variant = v >= 80 ? 8 : v;
-    mg_gemm_v8_set_warm(v >= 80 ? v - 80 : 1);
-}
+extern "C" void mg_gemm_set_variant(int v) { g_gemm_variant = v; }
 
 extern "C" int mg_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_t ldw,
                             const float* bias, int64_t M, int N, int K, int epilogue, void* out,

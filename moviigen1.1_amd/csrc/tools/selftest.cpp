@@ -707,7 +707,7 @@ int main(int argc, char** argv) {
         const int rounds = argc > 3 ? atoi(argv[3]) : 2;
         std::vector<int> vars;
         for (int i = 4; i < argc; ++i) vars.push_back(atoi(argv[i]));
-        if (vars.empty()) vars = {80, 81};
+        if (vars.empty()) vars = {8, 7};
         gemm_ab(Mg, 5120, 5120, 2, vars, rounds);      // self-attention o (+ gate, residual)
         gemm_ab(Mg, 5120, 13824, 2, vars, rounds);     // ffn.2 (+ gate, residual)
         gemm_ab(Mg, 5120, 5120, 0, vars, rounds);      // cross-attention q: store epilogue, the variants must tie

@@ -423,7 +423,7 @@ def test_operator_seam_flash_attention(dev, cfg):
     m.load_state_dict(W.make_dit_params(cfg, 0))
     m.to(dev)
     N, hd = cfg['num_heads'], cfg['dim'] // cfg['num_heads']
-    lat, ctx, t = W.randn((16, 2, 8, 12), 20).to(dev), W.randn((33, cfg['text_dim']), 30).to(dev), torch.tensor([999], device=dev)
+    lat, ctx, t = W.randn((16, 2, 8, 12), 20).to(dev), W.randn((29, cfg['text_dim']), 30).to(dev), torch.tensor([999], device=dev)
     base = m([lat], t=t, context=[ctx], seq_len=60)[0].clone()        # 48 video tokens inside seq_len 60: k_lens matters
     assert wm.flash_attention is engine_fa
     calls = []
