@@ -170,6 +170,59 @@ def test_vae_stage_partition():
     assert partition_costs([7], 1) == [0, 1]
 
 
+def test_vae_pipeline_host_logic():
+    """host side of the layer-pipelined decode (round 4): the chunk list is the single-GPU one, the activation shape a
+    cut receives is computed locally (no shape header travels), the cut is weighed by time, and the makespan model is the
+    pipeline recurrence."""
+    from wan.modules.vae import REL_MS_PER_MAC, WanVAE_, partition_costs, pipeline_makespan
+    v = WanVAE_(W.make_vae_params(8, 1), device='cpu')
+    assert v._chunks(21) == [1, 4, 4, 4, 4, 4] and v._chunks(10) == [1, 4, 4, 1] and v._chunks(1) == [1]
+    assert v._chunks(4, [1, 3]) == [1, 3]
+    st = v._stages()
+    n = len(st)
+    # dim-8 decoder: 32 -> 32 -> 16 -> 8 channels, x8 in space; frames x4 after the two temporal up-samplers (not on the first chunk)
+    assert v.stage_out_shape(1, 1, True, 6, 10) == (1, 6, 10, 32)
+    assert v.stage_out_shape(n, 1, True, 6, 10) == (1, 48, 80, 3)
+    assert v.stage_out_shape(n, 4, False, 6, 10) == (16, 48, 80, 3)
+    assert v.stage_out_shape(n - 1, 4, False, 6, 10) == (16, 48, 80, 8)
+    first_up = [i for i, s_ in enumerate(st) if s_[0] == 'up'][0]
+    assert v.stage_out_shape(first_up + 1, 4, False, 6, 10) == (8, 12, 20, 16)
+    assert v.stage_out_shape(first_up + 1, 1, True, 6, 10) == (1, 12, 20, 16)
+    # weights: MACs x the class factor, or the measured milliseconds as given
+    macs, wts = v.stage_costs(6, 10), v.stage_weights(6, 10)
+    kinds = [k for k, _, _ in st]
+    assert wts[kinds.index('attn')] == macs[kinds.index('attn')] * REL_MS_PER_MAC['attn']
+    assert wts[-1] == macs[-1] * REL_MS_PER_MAC['head'] and wts[-2] == macs[-2] * REL_MS_PER_MAC['narrow']
+    assert v.stage_weights(6, 10, stage_ms=list(range(1, n + 1))) == list(range(1, n + 1))
+    assert REL_MS_PER_MAC['wide'] == 1.0 and REL_MS_PER_MAC['head'] > REL_MS_PER_MAC['attn'] > 1.0
+    # the recurrence: one segment = the plain sum; balanced two-stage pipeline of 6 chunks = fill + 6 steady chunks
+    mk, eff = pipeline_makespan([3.0], [10.0], 6)
+    assert mk == 53.0 and abs(eff - 1.0) < 1e-12
+    mk, eff = pipeline_makespan([1.0, 1.0], [10.0, 10.0], 6)
+    assert mk == 61.0 and abs(eff - (2 + 100) / (2 * 61.0)) < 1e-12
+    mk2, _ = pipeline_makespan([1.0, 1.0], [10.0, 10.0], 6, xfer_ms=[5.0])
+    assert mk2 == mk + 5.0                                  # a transfer only adds latency while it is shorter than a segment
+    assert partition_costs(wts, 3)[0] == 0 and partition_costs(wts, 3)[-1] == n
+
+
+def test_collectives_have_one_test_transport_guard():
+    """every RCCL call of the product lives in wan/distributed/collectives.py, and the host-staged gloo transport of the
+    one-GPU multi-process tests is reachable through exactly one predicate."""
+    import re
+    dist_dir = os.path.join(ROOT, 'moviigen1.1_amd', 'wan', 'distributed')
+    for fn in os.listdir(dist_dir):
+        if not fn.endswith('.py') or fn in ('_test_transport.py', 'collectives.py'):
+            continue
+        src = open(os.path.join(dist_dir, fn)).read()
+        code = '\n'.join(ln.split('#')[0] for ln in src.split('"""')[::2] for ln in ln.splitlines())
+        assert "'gloo'" not in code and '"gloo"' not in code or fn == 'peer_copy.py', fn   # peer_copy: only the CPU flag of its fallback vote
+        assert '.cpu()' not in code or fn in ('peer_copy.py',), fn
+    col = open(os.path.join(dist_dir, 'collectives.py')).read()
+    assert len(re.findall(r'if _test_transport\.staged\(', col)) == 7          # all_to_all, all_gather, broadcast, send, recv, ring_hop, rendezvous
+    tt = open(os.path.join(dist_dir, '_test_transport.py')).read()
+    assert 'def staged(t, group):' in tt and "t.is_cuda and dist.get_backend(group) == 'gloo'" in tt
+
+
 def test_vae_upconv_option_host_side():
     """WanVAE_'s `upconv` keyword: validated at construction, and the layer-pipelined decode weighs the up-conv stages by
     what they execute (9 taps at 4x the pixels through the upsample, 16/9 as phase convs)."""
@@ -306,6 +359,14 @@ def test_bench_self_launch_command():
     assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and int(cmd[cmd.index('--master-port') + 1]) > 0
     i = cmd.index(os.path.join(ROOT, 'bench.py'))
     assert cmd[i + 1:] == ['--gpus', '8', '--steps', '3', '--warmup', '1']
+    # the command of BASELINE configs[3] ("FSDP shard + SP=4 on 8 GPUs"): every flag reaches the ranks, the transport
+    # choice travels in their environment too
+    r3 = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--workload', '1056p', '--dit-fsdp', '--vae-parallel',
+                         '--transport', 'peer_copy'], capture_output=True, text=True, timeout=300, env=env)
+    assert r3.returncode == 0, r3.stderr[-2000:]
+    cmd3 = json.loads([ln for ln in r3.stdout.splitlines() if ln.startswith('{')][0])['launch']
+    assert cmd3[cmd3.index(os.path.join(ROOT, 'bench.py')) + 1:] == ['--gpus', '8', '--workload', '1056p', '--dit-fsdp', '--vae-parallel',
+                                                                     '--transport', 'peer_copy']
     # under a launcher (WORLD_SIZE set) nothing is re-executed: the dry-run marker is not printed, the rank path runs
     # (and stops at the missing GPU here)
     env2 = dict(env, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
