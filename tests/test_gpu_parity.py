@@ -1389,6 +1389,24 @@ def test_fullsize_generate_call(dev):
     assert torch.equal(video3, video)
 
 
+def test_bench_live_traffic_measurement():
+    """bench.py's roofline.traffic leg: the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; --kernel-trace only) over
+    `mg_selftest attnpmc` at a small launch shape — the passes run, the kernel's dispatches are found in the counter CSV,
+    and the bytes are at least the algorithmic ones (q + k + v read once, o written once)."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('mg_bench', os.path.join(root, 'bench.py'))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    L, heads = 16384, 4
+    got, why = b.measure_attention_traffic(L, heads, timeout=300)
+    assert got is not None, why
+    alg = 4 * L * heads * 128 * 2
+    assert got['dispatches'] == [2, 2]
+    assert alg * 0.9 <= got['traffic_bytes_per_launch'] <= 40 * alg, (got, alg)
+
+
 def test_bench_refuses_more_ranks_than_gpus():
     """`python bench.py --gpus 2` on a 1-GPU box with the production backend: fails with ITS OWN message about
     visible GPUs (RCCL cannot place two ranks on one device) — not with a WORLD_SIZE assertion."""
