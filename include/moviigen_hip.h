@@ -315,6 +315,10 @@ int mg_vae_upconv_phases_f32(const float* x, int T, int H, int W, int Cin, const
  *       with Cout <= 4 (the decoder head, on v_mfma_f32_4x4x1_16B_f32) are exact in either mode. */
 #define MG_VAE_EXACT 0
 #define MG_VAE_BF16X3 1
+/* bits 8-9 of `mode` (measurement override, same bits out): 0 = the library picks the voxel tile of the wide exact convolutions
+ * by shape (256 voxels per workgroup for large launches, else 128), 1 << 8 = force 128, 2 << 8 = force 256. */
+#define MG_VAE_TILE_128 (1 << 8)
+#define MG_VAE_TILE_256 (2 << 8)
 
 /* RMS_norm over channels (F.normalize(x, dim=C) * sqrt(C) * gamma, vae.py:39-54), optional SiLU
  * (vae.py:193-197, 466-468).  x,out [rows][C] channels-last. */

@@ -102,16 +102,22 @@ MG_DEV void cv_epilogue(const ConvArgs& a, const f32x16_t (&acc)[NB], int64_t m_
 // cycles per 32-channel chunk and cout block instead of 16 of 64.  LDS rows keep their 144 bytes: 32 hi (64 B) | 32 lo
 // (64 B) | 16 B pad — fragment reads of 16 consecutive rows still land on 16 distinct 16-byte slots (9 r mod 16).
 // NOT the reference's arithmetic: results agree with the exact mode to ~1e-5 relative (test_vae_fast_mode), never the default.
-template <int NB, bool FAST = false>
+// MB = 128-voxel sub-tiles per workgroup (1 or 2): with MB = 2 a wave owns 2 x 32 voxels, every staged weight row and every
+// weight fragment read feeds twice the MFMAs (non-MFMA instructions per MFMA: 0.63 -> 0.44 at NB = 3, 0.56 -> 0.38 at NB = 4);
+// the price is LDS for one workgroup per CU instead of two.
+template <int NB, bool FAST = false, int MB = 1>
 __global__ __launch_bounds__(CV_THREADS) void vae_conv_kernel(const ConvArgs a) {
     constexpr int BN = NB ? 32 * NB : 4;
     constexpr int NW = NB ? NB : 1;                   // weight rows a thread stages per chunk (NB = 0: threads 0-31 stage the 4 rows)
+    constexpr int BM = CV_BM * MB;                    // voxels per workgroup
+    constexpr int NR = 4 * MB;                        // voxel rows a thread stages per chunk: rows (tid >> 3) + 32 i
     static_assert(NB || !FAST, "the Cout <= 4 form is exact only");
-    __shared__ __attribute__((aligned(16))) float smem[2 * (CV_BM + BN) * CV_LDS];
+    static_assert(NB || MB == 1, "the Cout <= 4 form uses the 128-voxel tile");
+    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * CV_LDS];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, l31 = lane & 31, g = lane >> 5;
-    const int64_t m0 = (int64_t)blockIdx.x * CV_BM;
+    const int64_t m0 = (int64_t)blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
     // Phase mode (mg_vae_upconv_phases_f32): "3x3 conv of the nearest-2x upsampled image" = four 2x2 convs of the image
     // itself, one per output parity (py, px): output row 2y+py reads upsampled rows 2y+py-1 .. 2y+py+1 = image rows
@@ -124,9 +130,9 @@ __global__ __launch_bounds__(CV_THREADS) void vae_conv_kernel(const ConvArgs a) 
 
     // ---- gather bookkeeping: this thread stages rows (tid>>3)+32i, float4 column tid&7 -----------
     const int ch4 = tid & 7;
-    int vt_[4], vy_[4], vx_[4];
+    int vt_[NR], vy_[NR], vx_[NR];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NR; ++i) {
         const int64_t m = m0 + (tid >> 3) + 32 * i;
         if (m < a.M) {
             const int64_t hw = (int64_t)a.Ho * a.Wo;
@@ -151,8 +157,8 @@ __global__ __launch_bounds__(CV_THREADS) void vae_conv_kernel(const ConvArgs a) 
     //   * a tap that falls into the zero padding (space, or time before the first cached frame) points at a page of zeros
     //     instead of being masked: no select, no multiply, no branch around the load;
     //   * chunk coordinates advance by counters, not divisions.
-    float4 ra[4], rw[NW];
-    const float* pa[4];                     // voxel rows of the tap being loaded (or the zero page)
+    float4 ra[NR], rw[NW];
+    const float* pa[NR];                    // voxel rows of the tap being loaded (or the zero page)
     const float* pw[NW];                    // weight rows, advanced by Cin per tap
     int ld_cc = 0, ld_dt = 0, ld_dy = 0, ld_dx = 0;                 // coordinates of the NEXT chunk to load (wave-uniform)
     const float* const base_neg = a.cache ? a.cache : a.x;          // frames before the chunk: the cache, if any
@@ -163,12 +169,12 @@ __global__ __launch_bounds__(CV_THREADS) void vae_conv_kernel(const ConvArgs a) 
     // dx<<6); a tap is valid when its three bits are set.  For the convolutions without the folded 2x upsample the row
     // pointer of a tap is then `frame base of the row` (recomputed when dt changes: every kh*kw taps) + a WAVE-UNIFORM
     // offset ((dy - kh/2) W + (dx - kw/2)) ldx — ~10 VALU per row and tap instead of ~40.
-    unsigned vmask[4];
-    const float* fbc[4];
-    const float* zp[4];                    // what an invalid tap reads: the zero page — or, for rows past M (never stored), row 0 of x:
+    unsigned vmask[NR];
+    const float* fbc[NR];
+    const float* zp[NR];                   // what an invalid tap reads: the zero page — or, for rows past M (never stored), row 0 of x:
                                             // the 1x1 GEMMs of the attention block index it with channel offsets far beyond the page
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NR; ++i) {
         unsigned mk = 0;
         const int valid = vt_[i] >= 0;                               // rows past M: every tap reads the zero page (never stored)
 #pragma unroll
@@ -186,7 +192,7 @@ __global__ __launch_bounds__(CV_THREADS) void vae_conv_kernel(const ConvArgs a) 
         if (!a.up2) {
             if ((ld_dy | ld_dx) == 0) {                              // wave-uniform: first tap of a temporal offset
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < NR; ++i) {
                     const int ti = vt_[i] + ld_dt - (a.kt - 1);
                     const int tt = max(ti >= 0 ? ti : a.tc + ti, 0);
                     const int vox = (tt * a.H + vy_[i]) * a.W + vx_[i];       // only dereferenced when the row's bits are set
@@ -195,14 +201,14 @@ __global__ __launch_bounds__(CV_THREADS) void vae_conv_kernel(const ConvArgs a) 
             }
             const int64_t off = (int64_t)((ld_dy + oy) * a.W + (ld_dx + ox)) * a.ldx;   // wave-uniform
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NR; ++i) {
                 const unsigned ok = (vmask[i] >> ld_dt) & (vmask[i] >> (3 + ld_dy)) & (vmask[i] >> (6 + ld_dx)) & 1u;
                 pa[i] = ok ? fbc[i] + off : zp[i];
             }
             return;
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NR; ++i) {
             const int ti = vt_[i] + ld_dt - (a.kt - 1);
             int yy = vy_[i] + ld_dy - a.kh / 2, xx = vx_[i] + ld_dx - a.kw / 2;
             const int ok = (vt_[i] >= 0) & (yy >= 0) & (yy < a.Ho) & (xx >= 0) & (xx < a.Wo) & ((ti >= 0) | (has_cache & (a.tc + ti >= 0)));
@@ -219,7 +225,7 @@ __global__ __launch_bounds__(CV_THREADS) void vae_conv_kernel(const ConvArgs a) 
         const bool c_ok = c_raw < a.Cin;                             // false only in the last chunk of a tap when Cin % 32 != 0
         const int c = c_ok ? c_raw : 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {          // (loaded as an ext-vector: a float4 struct copy from a selected pointer kept ra / rw in memory)
+        for (int i = 0; i < NR; ++i) {         // (loaded as an ext-vector: a float4 struct copy from a selected pointer kept ra / rw in memory)
             const f32x4_t t = *(const f32x4_t*)(pa[i] + c);                   // k >= Cin: finite data x zero weights
             ra[i] = make_float4(t[0], t[1], t[2], t[3]);
         }
@@ -248,17 +254,17 @@ __global__ __launch_bounds__(CV_THREADS) void vae_conv_kernel(const ConvArgs a) 
         *(uint2*)(r + 64 + ch4 * 8) = lo;
     };
     auto store_chunk = [&](int buf) __attribute__((always_inline)) {
-        float* sa = smem + buf * (CV_BM + BN) * CV_LDS;
-        float* sw = sa + CV_BM * CV_LDS;
+        float* sa = smem + buf * (BM + BN) * CV_LDS;
+        float* sw = sa + BM * CV_LDS;
         if (FAST) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) split_store(sa + ((tid >> 3) + 32 * i) * CV_LDS, ra[i]);
+            for (int i = 0; i < NR; ++i) split_store(sa + ((tid >> 3) + 32 * i) * CV_LDS, ra[i]);
 #pragma unroll
             for (int i = 0; i < NB; ++i) split_store(sw + ((tid >> 3) + 32 * i) * CV_LDS, rw[i]);
             return;
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *(float4*)(sa + ((tid >> 3) + 32 * i) * CV_LDS + ch4 * 4) = ra[i];
+        for (int i = 0; i < NR; ++i) *(float4*)(sa + ((tid >> 3) + 32 * i) * CV_LDS + ch4 * 4) = ra[i];
         if (NB == 0) {
             if (tid < 32) *(float4*)(sw + (tid >> 3) * CV_LDS + ch4 * 4) = rw[0];
             return;
@@ -267,11 +273,13 @@ __global__ __launch_bounds__(CV_THREADS) void vae_conv_kernel(const ConvArgs a) 
         for (int i = 0; i < NB; ++i) *(float4*)(sw + ((tid >> 3) + 32 * i) * CV_LDS + ch4 * 4) = rw[i];
     };
 
-    f32x16_t acc[NW];
+    f32x16_t acc[MB][NW];                             // [voxel sub-tile][cout block]: wave w owns rows 128 mb + 32 w + l31
 #pragma unroll
-    for (int i = 0; i < NW; ++i)
+    for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+        for (int i = 0; i < NW; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mb][i][e] = 0.f;
     f32x4_t acc4 = {0.f, 0.f, 0.f, 0.f};              // NB = 0: couts 0..3 of the lane's voxel, this lane half's share of k
 
     // K slice of this workgroup (ksplit: 1x1x1 GEMMs with few output tiles — P.V of the attention block): channel chunks
@@ -292,11 +300,11 @@ __global__ __launch_bounds__(CV_THREADS) void vae_conv_kernel(const ConvArgs a) 
         // front of the MFMA block (it can prove they touch the other buffer) and then waits for the loads right away
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        const float* sa = smem + (kc & 1) * (CV_BM + BN) * CV_LDS + (wave * 32 + l31) * CV_LDS + g * 4;
-        const float* sw = smem + (kc & 1) * (CV_BM + BN) * CV_LDS + CV_BM * CV_LDS + l31 * CV_LDS + g * 4;
+        const float* sa = smem + (kc & 1) * (BM + BN) * CV_LDS + (wave * 32 + l31) * CV_LDS + g * 4;      // sub-tile mb: + mb * 128 rows
+        const float* sw = smem + (kc & 1) * (BM + BN) * CV_LDS + BM * CV_LDS + l31 * CV_LDS + g * 4;
         if (NB == 0) {
             // A = weights: lane l holds w[cout l & 3][k]; B = voxels: lane l holds x[voxel l31][k]; block l >> 2 pairs them
-            const float* s4 = smem + (kc & 1) * (CV_BM + BN) * CV_LDS + CV_BM * CV_LDS + (lane & 3) * CV_LDS + g * 4;
+            const float* s4 = smem + (kc & 1) * (BM + BN) * CV_LDS + BM * CV_LDS + (lane & 3) * CV_LDS + g * 4;
 #pragma unroll
             for (int k8 = 0; k8 < 4; ++k8) {
                 const float4 xa = *(const float4*)(sa + k8 * 8);
@@ -312,21 +320,33 @@ __global__ __launch_bounds__(CV_THREADS) void vae_conv_kernel(const ConvArgs a) 
             const char* wa = (const char*)(sw - g * 4) + g * 16;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const bf16x8_t xh = *(const bf16x8_t*)(xa + ks * 32), xl = *(const bf16x8_t*)(xa + 64 + ks * 32);
+                bf16x8_t xh[MB], xl[MB];
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    xh[mb] = *(const bf16x8_t*)(xa + mb * 128 * CV_LDS * 4 + ks * 32);
+                    xl[mb] = *(const bf16x8_t*)(xa + mb * 128 * CV_LDS * 4 + 64 + ks * 32);
+                }
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
                     const bf16x8_t wh = *(const bf16x8_t*)(wa + nb * 32 * CV_LDS * 4 + ks * 32);
                     const bf16x8_t wl = *(const bf16x8_t*)(wa + nb * 32 * CV_LDS * 4 + 64 + ks * 32);
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh, acc[nb], 0, 0, 0);
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, acc[nb], 0, 0, 0);
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, acc[nb], 0, 0, 0);
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) {
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh[mb], acc[mb][nb], 0, 0, 0);
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl[mb], acc[mb][nb], 0, 0, 0);
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh[mb], acc[mb][nb], 0, 0, 0);
+                    }
                 }
             }
         } else
 #pragma unroll
         for (int k8 = 0; k8 < 4; ++k8) {
-            const float4 xa = *(const float4*)(sa + k8 * 8);
-            const float xv[4] = {xa.x, xa.y, xa.z, xa.w};
+            float xv[MB][4];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                const float4 xa = *(const float4*)(sa + mb * 128 * CV_LDS + k8 * 8);
+                xv[mb][0] = xa.x; xv[mb][1] = xa.y; xv[mb][2] = xa.z; xv[mb][3] = xa.w;
+            }
             float4 wv4[NW];
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) wv4[nb] = *(const float4*)(sw + nb * 32 * CV_LDS + k8 * 8);
@@ -335,7 +355,8 @@ __global__ __launch_bounds__(CV_THREADS) void vae_conv_kernel(const ConvArgs a) 
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
                     const float wv = s == 0 ? wv4[nb].x : s == 1 ? wv4[nb].y : s == 2 ? wv4[nb].z : wv4[nb].w;
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv, xv[s], acc[nb], 0, 0, 0);
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv, xv[mb][s], acc[mb][nb], 0, 0, 0);
                 }
             }
         }
@@ -345,18 +366,19 @@ __global__ __launch_bounds__(CV_THREADS) void vae_conv_kernel(const ConvArgs a) 
         __syncthreads();
     }
 
-    const int64_t m_in = m0 + wave * 32 + l31;
-    int64_t m_out = m_in;
-    if (a.phases && m_in < a.M) {
+    auto out_row = [&](int64_t m_in) __attribute__((always_inline)) {       // row of out / residual of conv-grid voxel m_in
+        if (!a.phases || m_in >= a.M) return m_in;
         const int64_t hw = (int64_t)a.H * a.W;
         const int t = (int)(m_in / hw);
         const int rem = (int)(m_in - (int64_t)t * hw);
         const int y = rem / a.W, x = rem - y * a.W;
-        m_out = ((int64_t)t * 2 * a.H + 2 * y + (ph >> 1)) * (2 * a.W) + 2 * x + (ph & 1);
-    }
+        return ((int64_t)t * 2 * a.H + 2 * y + (ph >> 1)) * (2 * a.W) + 2 * x + (ph & 1);
+    };
     if (NB == 0) {
         // the two lane halves hold the even / odd float4 of every 8 channels of the same voxel: add them, then lanes 0-31
         // apply (acc * scale + bias) + residual as cv_epilogue does and store the row's <= 4 couts
+        const int64_t m_in = m0 + wave * 32 + l31;
+        const int64_t m_out = out_row(m_in);
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc4[i] += __shfl_xor(acc4[i], 32, 64);
         if (g == 0 && m_in < a.M) {
@@ -370,14 +392,16 @@ __global__ __launch_bounds__(CV_THREADS) void vae_conv_kernel(const ConvArgs a) 
         }
         return;
     }
+    ConvArgs b = a;
     if (a.ksplit > 1) {     // raw partial sums of this K slice; vae_ksplit_reduce_kernel adds the slices in a fixed order
-        ConvArgs b = a;
         b.out = a.out + (int64_t)blockIdx.z * a.part_stride;
         b.bias = nullptr; b.residual = nullptr; b.out_scale = 1.f;
-        cv_epilogue<NW, 1>(b, acc, m_in, m_out, n0, g);
-        return;
     }
-    cv_epilogue<NW, 1>(a, acc, m_in, m_out, n0, g);
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        const int64_t m_in = m0 + mb * 128 + wave * 32 + l31;
+        cv_epilogue<NW, 1>(b, acc[mb], m_in, out_row(m_in), n0, g);
+    }
 }
 
 // out[m][n] = (sum over the K slices z of part[z][m][n]) (fixed order: deterministic), rows of n floats, n % 4 == 0
@@ -396,11 +420,8 @@ __global__ __launch_bounds__(256) void vae_ksplit_reduce_kernel(const float* __r
 // mode: MG_VAE_EXACT = fp32 MFMA (the reference's arithmetic), MG_VAE_BF16X3 = split-bf16 x 3 (opt-in fast mode) — an
 // argument of every call (ABI 7): two decodes on two streams or threads cannot change each other's arithmetic
 static int launch_conv(const ConvArgs& a, hipStream_t st, int mode) {
-    if (mode != MG_VAE_EXACT && mode != MG_VAE_BF16X3) return MG_ERR_ARG;
     if ((int64_t)(a.T > a.tc ? a.T : a.tc) * a.H * a.W > 0x7fffffffLL) return MG_ERR_SHAPE;   // 32-bit voxel index in the gather
     if (a.kt * a.kh * a.kw > 1 && a.Cin > 1024) return MG_ERR_SHAPE;                           // padding taps index the zero page by channel
-    const int64_t tiles_m = (a.M + CV_BM - 1) / CV_BM;
-    if (tiles_m > 0x7fffffffLL) return MG_ERR_SHAPE;
     int nb;
     if (a.Cout <= 4 && !a.phases && a.ksplit <= 1) nb = 0;        // the decoder head (96 -> 3): v_mfma_f32_4x4x1, exact in either mode
     else if (a.Cout <= 32) nb = 1;
@@ -409,6 +430,17 @@ static int launch_conv(const ConvArgs& a, hipStream_t st, int mode) {
     else nb = 4;
     const int bn = nb ? 32 * nb : 4;
     if (a.ksplit > 1 && (a.phases || a.kt * a.kh * a.kw != 1)) return MG_ERR_ARG;
+    // voxel tile: 256 (two 128-voxel sub-tiles per workgroup, MB = 2) for the wide exact convolutions with enough tiles to
+    // fill the chip twice over — weight staging and weight fragment reads are shared by twice the MFMAs —, else 128
+    const int tile_flag = mode >> 8;        // bits 8-9 of `mode`: 0 = by shape, 1 = force 128, 2 = force 256 (A/B measurements)
+    mode &= 0xff;
+    if (mode != MG_VAE_EXACT && mode != MG_VAE_BF16X3) return MG_ERR_ARG;
+    int mbt = (nb >= 3 && mode == MG_VAE_EXACT && a.ksplit <= 1 && a.M >= (int64_t)2 * 256 * 512) ? 2 : 1;
+    if (tile_flag == 1) mbt = 1;
+    if (tile_flag == 2 && nb >= 3 && mode == MG_VAE_EXACT && a.ksplit <= 1) mbt = 2;
+    const int bm = CV_BM * mbt;
+    const int64_t tiles_m = (a.M + bm - 1) / bm;
+    if (tiles_m > 0x7fffffffLL) return MG_ERR_SHAPE;
     const dim3 grid((unsigned)tiles_m, (unsigned)((a.Cout + bn - 1) / bn), a.phases ? 4u : a.ksplit > 1 ? (unsigned)a.ksplit : 1u), block(CV_THREADS);
     if (nb == 0) {
         hipLaunchKernelGGL((vae_conv_kernel<0, false>), grid, block, 0, st, a);
@@ -418,6 +450,11 @@ static int launch_conv(const ConvArgs& a, hipStream_t st, int mode) {
         if (nb == 1) hipLaunchKernelGGL((vae_conv_kernel<1, true>), grid, block, 0, st, a);
         else if (nb == 3) hipLaunchKernelGGL((vae_conv_kernel<3, true>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((vae_conv_kernel<4, true>), grid, block, 0, st, a);
+        return mg_check_launch();
+    }
+    if (mbt == 2) {
+        if (nb == 3) hipLaunchKernelGGL((vae_conv_kernel<3, false, 2>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((vae_conv_kernel<4, false, 2>), grid, block, 0, st, a);
         return mg_check_launch();
     }
     if (nb == 1) hipLaunchKernelGGL((vae_conv_kernel<1, false>), grid, block, 0, st, a);

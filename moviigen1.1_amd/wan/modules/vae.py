@@ -34,7 +34,7 @@ class WanVAE_:
     """decoder-side container: parameters keyed by the reference state_dict names, repacked for
     the channels-last kernels ([Cout,Cin,kt,kh,kw] -> [Cout,kt,kh,kw,Cin])."""
 
-    def __init__(self, state_dict, z_dim=16, device='cuda', upconv='phases', mode='exact'):
+    def __init__(self, state_dict, z_dim=16, device='cuda', upconv='phases', mode='exact', tile='auto'):
         """upconv: how the 3x3 conv behind a nearest-2x upsample runs — 'phases' = four 2x2 convs of the image with
         pre-summed taps (4/9 of the multiply-adds; default), 'gather' = the 3x3 conv reading through the upsample (the two
         agree to fp32 rounding of the weight sums; kept as the cross-check)."""
@@ -44,7 +44,10 @@ class WanVAE_:
             raise ValueError(f"mode must be 'exact' (the reference's fp32 arithmetic) or 'bf16x3', got {mode!r}")
         self.upconv = upconv
         self.mode = mode          # 'bf16x3': opt-in split-bf16 convolutions (~1e-5 relative per conv)
-        self._conv_mode = ops.VAE_BF16X3 if mode == 'bf16x3' else ops.VAE_EXACT    # passed with every conv call (ABI 7)
+        if tile not in ('auto', 128, 256):
+            raise ValueError(f"tile must be 'auto', 128 or 256 (voxels per workgroup of the wide exact convolutions), got {tile!r}")
+        # passed with every conv call (ABI 7): the arithmetic mode, and in bits 8-9 the measurement override of the voxel tile
+        self._conv_mode = (ops.VAE_BF16X3 if mode == 'bf16x3' else ops.VAE_EXACT) | ({'auto': 0, 128: 1, 256: 2}[tile] << 8)
         self.z_dim = z_dim
         self.device = torch.device(device)
         self.P = {}
@@ -406,7 +409,7 @@ def partition_costs(costs, parts):
 class WanVAE:
 
     def __init__(self, z_dim=16, vae_pth='cache/vae_step_411000.pth', dtype=torch.float, device='cuda',
-                 state_dict=None, upconv='phases', mode='exact'):
+                 state_dict=None, upconv='phases', mode='exact', tile='auto'):
         if dtype not in (torch.float, torch.float32):
             raise NotImplementedError('the reference decodes in fp32 (vae.py:623,658); so does this engine')
         self.dtype = dtype
@@ -414,7 +417,7 @@ class WanVAE:
         if state_dict is None:
             logging.info(f'loading {vae_pth}')
             state_dict = torch.load(vae_pth, map_location='cpu', weights_only=True)
-        self.model = WanVAE_(state_dict, z_dim=z_dim, device=device, upconv=upconv, mode=mode)
+        self.model = WanVAE_(state_dict, z_dim=z_dim, device=device, upconv=upconv, mode=mode, tile=tile)
         self.mean, self.std = torch.tensor(_MEAN[:z_dim]), torch.tensor(_STD[:z_dim])
         self.scale = [self.mean, 1.0 / self.std]
 

@@ -259,6 +259,30 @@ def test_attention_prescaled_q(dev, attn_variant):
     assert (outs[False][1] - torch.logsumexp(s, -1)).abs().max().item() < 5e-2
 
 
+def test_attention_reserved_cus_same_bits(dev):
+    """mg_attn_fwd_bf16_hd128_prescaled(..., reserve_cus): a persistent grid that leaves 8 / 64 CUs free (what a sequence-
+    parallel layer may ask for while an exchange kernel is in flight) walks the same (head, query block) items on fewer
+    workgroups — the result must be the same bits; a negative count is refused."""
+    from wan.backend import lib, ops
+    L, N = 20000, 4                                        # 79 query blocks x 4 heads = 316 items > 256 CUs: the persistent path
+    gen = torch.Generator(device=dev).manual_seed(5)
+    q = (torch.randn(L, N * 128, device=dev, generator=gen) * 0.3).bfloat16()
+    k = torch.randn(L, N * 128, device=dev, generator=gen).bfloat16()
+    v = torch.randn(L, N * 128, device=dev, generator=gen).bfloat16()
+    n_pk = ops.packed_kv_numel(L, N)
+    kp, vp = torch.empty(n_pk, dtype=torch.bfloat16, device=dev), torch.empty(n_pk, dtype=torch.bfloat16, device=dev)
+    ops.pack_kv(k, v, N, kp, vp)
+    outs = []
+    for rs in (0, 8, 64):
+        o = torch.zeros(L, N * 128, dtype=torch.bfloat16, device=dev)
+        ops.attention_hd128(q, kp, vp, o, L, N, 1.0, prescaled=True, reserve_cus=rs)
+        outs.append(o)
+    assert torch.isfinite(outs[0].float()).all().item() and outs[0].float().abs().max().item() > 0
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    with pytest.raises(lib.MoviigenHipError):
+        ops.attention_hd128(q, kp, vp, outs[0], L, N, 1.0, prescaled=True, reserve_cus=-1)
+
+
 @pytest.fixture(params=[0, 3], ids=['m16', 'w64'])
 def attn_variant(request):
     """run a test under every kernel selection of mg_attn_fwd_bf16_hd128."""
@@ -868,6 +892,32 @@ def test_vae_upconv_phases(dev, cin, cout, T, H, W):
     ref = _conv_ref_f64(x, None, w, b, pts, True)
     sel = torch.stack([got[t, y, xx] for (t, y, xx) in pts]).double().cpu()
     assert ((sel - ref).abs().max() / ref.abs().max()).item() < 1e-5
+
+
+@pytest.mark.parametrize('cin,cout,T,H,Wd,tc,phases', [(96, 96, 3, 37, 53, 2, False), (192, 192, 2, 30, 41, 1, False), (64, 384, 1, 19, 23, 0, False),
+                                                        (192, 96, 2, 21, 33, 0, True)])
+def test_vae_conv_voxel_tiles_agree(dev, cin, cout, T, H, Wd, tc, phases):
+    """the 256-voxel workgroup tile of the wide exact convolutions (two 128-voxel sub-tiles sharing the staged weights;
+    what the library picks for large launches) against the 128-voxel one: the same accumulation order per voxel, so
+    the SAME BITS — with a ragged last tile (M not a multiple of 256), cache frames, residual, cout tails, and the four
+    phase convolutions of an up-conv."""
+    from wan.backend import ops
+    gen = torch.Generator(device=dev).manual_seed(cin + cout)
+    x = torch.randn(T, H, Wd, cin, device=dev, generator=gen)
+    b = torch.randn(cout, device=dev, generator=gen)
+    outs = []
+    for flag in (1 << 8, 2 << 8, 0):
+        if phases:
+            wp = ops.vae_upconv_fold_weights(torch.randn(cout, 1, 3, 3, cin, device=dev, generator=torch.Generator(device=dev).manual_seed(3)) / math.sqrt(9 * cin))
+            outs.append(ops.vae_upconv_phases(x, wp, b, torch.full((T, 2 * H, 2 * Wd, cout), float('nan'), device=dev), mode=ops.VAE_EXACT | flag))
+        else:
+            w = torch.randn(cout, 3, 3, 3, cin, device=dev, generator=torch.Generator(device=dev).manual_seed(3)) / math.sqrt(27 * cin)
+            cache = torch.randn(tc, H, Wd, cin, device=dev, generator=torch.Generator(device=dev).manual_seed(4)) if tc else None
+            res = torch.randn(T, H, Wd, cout, device=dev, generator=torch.Generator(device=dev).manual_seed(5))
+            o = torch.full((T, H, Wd, cout), float('nan'), device=dev)
+            outs.append(ops.vae_conv(x, w, b, o, 3, 3, 3, cache=cache, residual=res, mode=ops.VAE_EXACT | flag))
+    assert torch.isfinite(outs[0]).all().item()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
 def test_vae_fast_mode(dev, golden):
