@@ -102,9 +102,9 @@ MG_DEV void cv_epilogue(const ConvArgs& a, const f32x16_t (&acc)[NB], int64_t m_
 // cycles per 32-channel chunk and cout block instead of 16 of 64.  LDS rows keep their 144 bytes: 32 hi (64 B) | 32 lo
 // (64 B) | 16 B pad — fragment reads of 16 consecutive rows still land on 16 distinct 16-byte slots (9 r mod 16).
 // NOT the reference's arithmetic: results agree with the exact mode to ~1e-5 relative (test_vae_fast_mode), never the default.
-// MB = 128-voxel sub-tiles per workgroup (1 or 2): with MB = 2 a wave owns 2 x 32 voxels, every staged weight row and every
-// weight fragment read feeds twice the MFMAs (non-MFMA instructions per MFMA: 0.63 -> 0.44 at NB = 3, 0.56 -> 0.38 at NB = 4);
-// the price is LDS for one workgroup per CU instead of two.
+// MB = 128-voxel sub-tiles per workgroup (1 = what runs; 2 = measurement variant, see launch_conv): with MB = 2 a wave owns
+// 2 x 32 voxels, every staged weight row and every weight fragment read feeds twice the MFMAs (non-MFMA instructions per MFMA:
+// 0.63 -> 0.44 at NB = 3, 0.56 -> 0.38 at NB = 4); the price is LDS for one workgroup per CU instead of two — and it loses.
 template <int NB, bool FAST = false, int MB = 1>
 __global__ __launch_bounds__(CV_THREADS) void vae_conv_kernel(const ConvArgs a) {
     constexpr int BN = NB ? 32 * NB : 4;
@@ -430,14 +430,14 @@ static int launch_conv(const ConvArgs& a, hipStream_t st, int mode) {
     else nb = 4;
     const int bn = nb ? 32 * nb : 4;
     if (a.ksplit > 1 && (a.phases || a.kt * a.kh * a.kw != 1)) return MG_ERR_ARG;
-    // voxel tile: 256 (two 128-voxel sub-tiles per workgroup, MB = 2) for the wide exact convolutions with enough tiles to
-    // fill the chip twice over — weight staging and weight fragment reads are shared by twice the MFMAs —, else 128
-    const int tile_flag = mode >> 8;        // bits 8-9 of `mode`: 0 = by shape, 1 = force 128, 2 = force 256 (A/B measurements)
+    // voxel tile: 128 per workgroup.  The 256-voxel form (MB = 2: weight staging and weight fragment reads shared by twice the
+    // MFMAs, 0.63 -> 0.44 non-MFMA instructions per MFMA at NB = 3) is kept behind MG_VAE_TILE_256 for A/B runs only: it needs the
+    // LDS of a whole CU, and with ONE workgroup per CU nothing fills the barrier and load-latency bubbles that a second
+    // workgroup fills today — the 1920x832x81f decode takes 9.59 s with it against 8.93 s (profiles/r04e_vae_tiles.log).
+    const int tile_flag = mode >> 8;        // bits 8-9 of `mode`: 0 / MG_VAE_TILE_128 = 128 voxels, MG_VAE_TILE_256 = 256 (measurements)
     mode &= 0xff;
     if (mode != MG_VAE_EXACT && mode != MG_VAE_BF16X3) return MG_ERR_ARG;
-    int mbt = (nb >= 3 && mode == MG_VAE_EXACT && a.ksplit <= 1 && a.M >= (int64_t)2 * 256 * 512) ? 2 : 1;
-    if (tile_flag == 1) mbt = 1;
-    if (tile_flag == 2 && nb >= 3 && mode == MG_VAE_EXACT && a.ksplit <= 1) mbt = 2;
+    const int mbt = (tile_flag == 2 && nb >= 3 && mode == MG_VAE_EXACT && a.ksplit <= 1) ? 2 : 1;
     const int bm = CV_BM * mbt;
     const int64_t tiles_m = (a.M + bm - 1) / bm;
     if (tiles_m > 0x7fffffffLL) return MG_ERR_SHAPE;

@@ -45,7 +45,8 @@ class WanVAE_:
         self.upconv = upconv
         self.mode = mode          # 'bf16x3': opt-in split-bf16 convolutions (~1e-5 relative per conv)
         if tile not in ('auto', 128, 256):
-            raise ValueError(f"tile must be 'auto', 128 or 256 (voxels per workgroup of the wide exact convolutions), got {tile!r}")
+            raise ValueError(f"tile must be 'auto' (= 128), 128 or 256 (voxels per workgroup of the wide exact convolutions; 256 is the slower "
+                             f"measurement variant), got {tile!r}")
         # passed with every conv call (ABI 7): the arithmetic mode, and in bits 8-9 the measurement override of the voxel tile
         self._conv_mode = (ops.VAE_BF16X3 if mode == 'bf16x3' else ops.VAE_EXACT) | ({'auto': 0, 128: 1, 256: 2}[tile] << 8)
         self.z_dim = z_dim
