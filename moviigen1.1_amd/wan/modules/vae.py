@@ -262,7 +262,7 @@ class WanVAE_:
         """what the pipelined decode balances: measured milliseconds per stage and steady-state chunk when given
         (tools/bench_vae.py --stages prints them for a size), else MACs x the measured cost per MAC of the stage's kernel
         class (REL_MS_PER_MAC: the 96-channel stage runs at a different efficiency than the 384-channel ones, the Cout = 3
-        head burns 29 of 32 MFMA columns, the attention block is three small launches per 2048 query rows)."""
+        head re-reads its input 27 times for 3 output channels, the attention block is three launches per 2048 query rows)."""
         if stage_ms is not None:
             assert len(stage_ms) == len(self._stages())
             return list(stage_ms)
@@ -360,7 +360,7 @@ class WanVAE_:
 #   narrow = the 96-channel stage (vae_conv_kernel<3>: three of four MFMA column blocks of a 128-wide tile),
 #   up   = Resample stages (time_conv 3x1x1 + the four 2x2 phase convs + interleave),
 #   attn = the per-frame attention block (qkv / proj 1x1 convs + score blocks of 2048 rows + row softmax),
-#   head = RMS_norm + SiLU + the 96 -> 3 convolution (vae_conv_kernel<1>).
+#   head = RMS_norm + SiLU + the 96 -> 3 convolution (vae_conv_kernel<0> on v_mfma_f32_4x4x1: bound by its 27-tap input re-read).
 REL_MS_PER_MAC = {'wide': 1.0, 'narrow': 1.06, 'up': 1.08, 'attn': 1.5, 'head': 11.7}
 
 
