@@ -363,8 +363,12 @@ int mg_vae_time_interleave_f32(const float* x, int T, int64_t HW, int C, float* 
  * schedules for A/B measurements.  All are process-global switches; passing NULL / 0 restores the default.
  * ---------------------------------------------------------------------------------------- */
 /* Tile schedule of mg_gemm_bf16 (same results bit for bit) — a process-global MEASUREMENT / TEST switch, not part of
- * the drop-in contract and not thread-safe; the default (0) selects by shape (8 for M > 256 and N > 128, else 2 / 1):
- * 8 = 256x256x64 tile, v_mfma_f32_16x16x32_bf16, persistent loop (one workgroup per CU; the first k-tile of the next
+ * the drop-in contract and not thread-safe; the default (0) selects by shape (11 for M > 256 and N > 128, else 2 / 1):
+ * 11 = 256x256x64 tile, v_mfma_f32_16x16x32_bf16, persistent loop, 4 waves = ONE per SIMD (128x128 each); the k-tile is a
+ *     GENERATED instruction schedule (tools/gen_gemm_v11_schedule.py): buffer_load ... lds with one 32-bit offset per piece,
+ *     at most one other instruction behind each MFMA, counted lgkmcnt waits, the last 32 MFMAs of a k-tile behind the next
+ *     k-tile's barrier; two schedules by K (110 + flags selects it with its experiment flags);
+ * 8 = (the round-3 default, A/B partner) 256x256x64 tile, v_mfma_f32_16x16x32_bf16, persistent loop (one workgroup per CU; the first k-tile of the next
  *     tile is fetched during the last k-tile of the current one), EIGHT waves in two ping-pong groups: in every interval
  *     between two barriers one group issues 16 MFMAs per wave while its SIMD partners read fragments and issue LDS-DMA;
  * 7 = the same tile and loop with 4 waves = ONE per SIMD (128x128 each), LDS-DMA pieces and fragment reads spread

@@ -702,6 +702,11 @@ int main(int argc, char** argv) {
         test_gemm(Mg, 5120, 13824, 2, 128, true);     // ffn.2 (+ gate, residual)
         return n_fail ? 1 : 0;
     }
+    if (argc > 1 && !strcmp(argv[1], "gemmv")) {   // gemmv variant M N K [epi]: one shape, every sample row checked
+        mg_gemm_set_variant(atoi(argv[2]));
+        test_gemm(atoll(argv[3]), atoi(argv[4]), atoi(argv[5]), argc > 6 ? atoi(argv[6]) : 0, 512, false);
+        return n_fail ? 1 : 0;
+    }
     if (argc > 1 && !strcmp(argv[1], "gemmab")) {   // gemmab M rounds v1 v2 ...: the three residual / one store GEMM of a block, variants alternating
         const int64_t Mg = argc > 2 ? atoll(argv[2]) : 131040;
         const int rounds = argc > 3 ? atoi(argv[3]) : 2;
@@ -724,7 +729,13 @@ int main(int argc, char** argv) {
         test_gemm(argc > 3 ? atoll(argv[3]) : 75600, argc > 4 ? atoi(argv[4]) : 5120, argc > 5 ? atoi(argv[5]) : 5120, 0, 64, true);
         unsigned long long h[64];
         CK(hipMemcpy(h, buf, sizeof h, hipMemcpyDeviceToHost));
-        if (gv >= 8) {      // ping-pong kernels: waves 0-3 = group X, 4-7 = group Y; per PHASE (4 phases = one k-tile of 64 MFMAs per wave)
+        if (gv == 11 || gv >= 110) {      // variant 11: 4 waves x {barrier, to the first MFMA, k-step 0, k-step 1, k-tiles}
+            for (int w = 0; w < 4; ++w) {
+                const double n = (double)h[w * 5 + 4];
+                printf("wave %d: k-tiles %.0f  vmcnt+barrier %.0f  to first MFMA %.0f  k-step 0 %.0f  k-step 1 %.0f  sum %.0f (cycles per k-tile)\n", w, n,
+                       h[w * 5] / n, h[w * 5 + 1] / n, h[w * 5 + 2] / n, h[w * 5 + 3] / n, (h[w * 5] + h[w * 5 + 1] + h[w * 5 + 2] + h[w * 5 + 3]) / n);
+            }
+        } else if (gv >= 8) {      // ping-pong kernels: waves 0-3 = group X, 4-7 = group Y; per PHASE (4 phases = one k-tile of 64 MFMAs per wave)
             for (int w = 0; w < 8; ++w) {
                 const double n = (double)h[w * 5 + 4];
                 printf("wave %d: phases %.0f  load part %.0f  barrier-1 wait %.0f  MFMA part %.0f  barrier-2 wait %.0f  (cycles per phase; x4 per k-tile)\n",

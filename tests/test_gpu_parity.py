@@ -133,14 +133,16 @@ def test_gemm_tile_variants_agree(dev, M, N, K):
     """the tile schedules (128x128, 256x128, 256x256 with one wave per SIMD: one tile per workgroup, and the persistent
     tile loop — the last three shapes have more tiles than CUs, so its workgroups iterate: two with < 32 tile columns = the
     chip-wide 8x32 super-tile raster of variant 8, incl. a partial band, one with 33 = the per-XCD band raster, one narrow with
-    K > 8192 = the 16x16 super-tile raster) give the same bits, ragged edges included."""
+    K > 8192 = the 16x16 super-tile raster — and the default, variant 11: variant 7's structure with a generated k-tile schedule,
+    buffer loads straight to LDS and the rotated tail; K = 64 is its one-k-tile case, K = 8256 its second schedule) give the same
+    bits, ragged edges included."""
     from wan.backend import lib, ops
     a = W.randn((M, K), 16).bfloat16().to(dev)
     w = (W.randn((N, K), 17) * 0.05).bfloat16().to(dev)
     b = W.randn((N,), 18).to(dev)
     outs = []
     try:
-        for v in (0, 1, 2, 7, 8):
+        for v in (0, 1, 2, 7, 8, 11):
             lib.load().mg_gemm_set_variant(v)
             o = torch.full((M + 1, N), -7.0, dtype=torch.float32, device=dev)      # guard row: no write past M
             ops.gemm(a, w, b, ops.BIAS_F32, o[:M])
