@@ -242,6 +242,7 @@ static void test_gemm(int64_t M, int N, int K, int epi, int nsamp, bool timeit) 
     double err = rc ? 1e9 : 0;
     const int64_t total = M * N;
     const int64_t cnt = nsamp > 0 ? nsamp : total;
+    int n_bad = 0;
     for (int64_t s = 0; s < cnt; ++s) {
         int64_t m, n;
         if (nsamp > 0) {
@@ -259,6 +260,12 @@ static void test_gemm(int64_t M, int N, int K, int epi, int nsamp, bool timeit) 
         else if (epi == MG_EPI_GATE_RESID_F32) { ref = resid0[(size_t)m * ldo + n] + y * gate[n]; got = hf[(size_t)m * ldo + n]; }
         else { ref = y; got = hf[(size_t)m * ldo + n]; }
         err = fmax(err, fabs(got - ref) / fmax(1.0, fabs(ref)));
+        if (getenv("MG_GEMM_SHOW_BAD") && n_bad < 12 && fabs(got - ref) / fmax(1.0, fabs(ref)) > 2e-2) {
+            ++n_bad;
+            printf("    bad (m %lld, n %lld): got %.6f want %.6f  y %.6f%s\n", (long long)m, (long long)n, got, ref, y,
+                   epi == MG_EPI_GATE_RESID_F32 ? "" : "");
+            if (epi == MG_EPI_GATE_RESID_F32) printf("        resid %.6f gate %.6f\n", resid0[(size_t)m * ldo + n], gate[n]);
+        }
     }
     char nm[160];
     snprintf(nm, sizeof nm, "gemm_bf16 M%lld N%d K%d epi%d", (long long)M, N, K, epi);
@@ -702,6 +709,35 @@ int main(int argc, char** argv) {
         test_gemm(Mg, 5120, 13824, 2, 128, true);     // ffn.2 (+ gate, residual)
         return n_fail ? 1 : 0;
     }
+    if (argc > 1 && !strcmp(argv[1], "gemmdiff")) {   // gemmdiff variant M N K epi: every element against variant 8, mismatches by position in the wave's block
+        const int var = atoi(argv[2]);
+        const int64_t M = atoll(argv[3]);
+        const int N = atoi(argv[4]), K = atoi(argv[5]), epi = atoi(argv[6]);
+        auto A = randbf((size_t)M * K), Wt = randbf((size_t)N * K, 0.05f);
+        auto bias = randf(N), gate = randf(N);
+        auto r0 = randf((size_t)M * N);
+        Dev<uint16_t> dA(A), dW(Wt);
+        Dev<float> db(bias), dg(gate), o1(r0), o2(r0);
+        mg_gemm_set_variant(8);
+        int rc = mg_gemm_bf16(dA.p, K, dW.p, K, db.p, M, N, K, epi, o1.p, N, dg.p, 0);
+        mg_gemm_set_variant(var);
+        rc |= mg_gemm_bf16(dA.p, K, dW.p, K, db.p, M, N, K, epi, o2.p, N, dg.p, 0);
+        CK(hipDeviceSynchronize());
+        auto h1 = o1.host(), h2 = o2.host();
+        long bad = 0, by_c[8] = {0}, by_e[4] = {0}, by_j[8] = {0}, by_G[4] = {0}, by_r[16] = {0}, by_w[4] = {0};
+        for (int64_t m = 0; m < M; ++m)
+            for (int n = 0; n < N; ++n)
+                if (h1[(size_t)m * N + n] != h2[(size_t)m * N + n]) {
+                    if (bad < 8) printf("  (m %lld, n %d): variant 8 %.6f  variant %d %.6f  resid %.6f\n", (long long)m, n, h1[(size_t)m * N + n], var, h2[(size_t)m * N + n], r0[(size_t)m * N + n]);
+                    ++bad;
+                    const int mm = (int)(m & 127), nn = n & 127;
+                    ++by_c[nn >> 4], ++by_e[nn & 3], ++by_G[(nn >> 2) & 3], ++by_j[mm >> 4], ++by_r[mm & 15], ++by_w[((m >> 7) & 1) * 2 + ((n >> 7) & 1)];
+                }
+        printf("rc %d: %ld of %lld elements differ\n", rc, bad, (long long)(M * N));
+        auto show = [](const char* nm, long* v, int k) { printf("  by %s:", nm); for (int i = 0; i < k; ++i) printf(" %ld", v[i]); printf("\n"); };
+        show("feature block c", by_c, 8); show("element e", by_e, 4); show("G", by_G, 4); show("token block j", by_j, 8); show("r16", by_r, 16); show("wave", by_w, 4);
+        return bad ? 1 : 0;
+    }
     if (argc > 1 && !strcmp(argv[1], "gemmv")) {   // gemmv variant M N K [epi]: one shape, every sample row checked
         mg_gemm_set_variant(atoi(argv[2]));
         test_gemm(atoll(argv[3]), atoi(argv[4]), atoi(argv[5]), argc > 6 ? atoi(argv[6]) : 0, 512, false);
@@ -734,6 +770,11 @@ int main(int argc, char** argv) {
                 const double n = (double)h[w * 5 + 4];
                 printf("wave %d: k-tiles %.0f  vmcnt+barrier %.0f  to first MFMA %.0f  k-step 0 %.0f  k-step 1 %.0f  sum %.0f (cycles per k-tile)\n", w, n,
                        h[w * 5] / n, h[w * 5 + 1] / n, h[w * 5 + 2] / n, h[w * 5 + 3] / n, (h[w * 5] + h[w * 5 + 1] + h[w * 5 + 2] + h[w * 5 + 3]) / n);
+                // 32 + 3w: {whole kernel, tail + epilogue, tiles}, summed over the workgroups
+                const double tiles = (double)h[32 + w * 3 + 2], tot = (double)h[32 + w * 3], epi = (double)h[32 + w * 3 + 1];
+                const double loop = (double)(h[w * 5] + h[w * 5 + 1] + h[w * 5 + 2] + h[w * 5 + 3]);
+                printf("        per tile: %.0f cycles = k-loop %.0f + tail/epilogue %.0f + rest %.0f   (%.0f tiles)\n", tot / tiles, loop / tiles,
+                       epi / tiles, (tot - loop - epi) / tiles, tiles);
             }
         } else if (gv >= 8) {      // ping-pong kernels: waves 0-3 = group X, 4-7 = group Y; per PHASE (4 phases = one k-tile of 64 MFMAs per wave)
             for (int w = 0; w < 8; ++w) {

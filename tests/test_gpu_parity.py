@@ -153,6 +153,35 @@ def test_gemm_tile_variants_agree(dev, M, N, K):
     assert all(torch.equal(outs[0], o) for o in outs[1:])
 
 
+@pytest.mark.parametrize('M,N,K', [(1030, 1284, 640), (4200, 4100, 128), (9000, 2304, 64), (2100, 8448, 8256)])
+@pytest.mark.parametrize('epi', [0, 1, 2, 3])
+def test_gemm_default_epilogues_match_direct_ones(dev, M, N, K, epi):
+    """variant 11 (the default for M > 256, N > 128) has its own epilogues — bf16 outputs: W rows staged in a permuted order so that
+    a lane stores 8 consecutive features (16 bytes); fp32 outputs: the wave's block transposed through LDS and written as whole row
+    segments, with the residual read the same way — against variant 8's direct epilogue: EVERY element, bit for bit, full and ragged
+    blocks, one k-tile and both k-loop schedules, outputs with a row pitch > N, and a bf16 pitch that only allows 8-byte stores (the
+    launcher's fallback)."""
+    from wan.backend import lib, ops
+    a = W.randn((M, K), 26).bfloat16().to(dev)
+    w = (W.randn((N, K), 27) * 0.05).bfloat16().to(dev)
+    b, g = W.randn((N,), 28).to(dev), W.randn((N,), 29).to(dev)
+    f32 = epi >= 2
+    for pitch in (N, N + 24, N + 4):
+        r0 = W.randn((M + 1, pitch), 30).to(dev)
+        outs = []
+        try:
+            for v in (8, 11):
+                lib.load().mg_gemm_set_variant(v)
+                o = r0.clone() if f32 else r0.bfloat16()
+                ops.gemm(a, w, b, epi, o[:M, :N], gate=g if epi == 2 else None)
+                outs.append(o)
+        finally:
+            lib.load().mg_gemm_set_variant(lib.DEFAULT_GEMM_VARIANT)
+        assert torch.equal(outs[0], outs[1]), (pitch, (outs[0].float() - outs[1].float()).abs().max().item())
+        ref = r0 if f32 else r0.bfloat16()
+        assert torch.equal(outs[1][M], ref[M]) and torch.equal(outs[1][:, N:], ref[:, N:])      # nothing outside [M, N]
+
+
 def test_gemm_rejects_bad_shapes(dev):
     from wan.backend import lib, ops
     a = torch.zeros(8, 96, dtype=torch.bfloat16, device=dev)      # K % 64 != 0

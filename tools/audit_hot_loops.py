@@ -97,12 +97,57 @@ def audit(src, frag, skip, n_mfma, max_other):
     return report, problems
 
 
+def regs(op):
+    """the VGPR numbers an assembly operand names: v7 -> {7}, v[4:7] -> {4, 5, 6, 7}"""
+    m = re.fullmatch(r'v\[(\d+):(\d+)\]', op)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.fullmatch(r'v(\d+)', op)
+    return {int(m.group(1))} if m else set()
+
+
+def store_hazards(src):
+    """A wide store directly followed by a PACKED-fp32 VALU instruction that overwrites its data registers: hipcc leaves no wait
+    state there for ds_write* and for buffer stores with a scalar offset register, and on gfx950 the store picks up part of the new
+    value in four lanes of every 16 (found in the row-wise epilogue of GEMM variant 11; csrc/gemm_bf16_v11.hip).  Scans EVERY kernel
+    of a source file; returns a list of 'kernel: store / next instruction' strings."""
+    out = []
+    text = device_asm(src)
+    funcs = re.split(r'^(_Z\w+|\w+_kernel\w*):', text, flags=re.M)
+    for name, body in zip(funcs[1::2], funcs[2::2]):
+        lines = [ln.strip() for ln in body.split('.Lfunc_end')[0].splitlines()
+                 if ln.startswith('\t') and not ln.strip().startswith((';', '.'))]
+        for a, b in zip(lines, lines[1:]):
+            op = a.split()[0]
+            if not op.startswith(('buffer_store_', 'global_store_', 'flat_store_', 'scratch_store_', 'ds_write')):
+                continue
+            if not b.startswith('v_pk_'):
+                continue
+            ops = [o.strip() for o in a[len(op):].split(',')]
+            if op.startswith('buffer_store_'):
+                data = regs(ops[0])
+            elif op.startswith('ds_write'):
+                data = set().union(*[regs(o.split()[0]) for o in ops[1:] if o.split()])
+            else:
+                data = regs(ops[1]) if len(ops) > 1 else set()
+            dst = regs(b[len(b.split()[0]):].split(',')[0].strip())
+            if len(data) >= 3 and data & dst:          # more than 64 bits of store data (64-bit stores: no failure observed)
+                out.append(f'{name[:60]}: `{a}` directly followed by `{b}`')
+    return out
+
+
 def main():
     allp = []
     for k in KERNELS:
         rep, prob = audit(*k)
         print('\n'.join(rep))
         allp += prob
+    n_src = 0
+    for src in sorted(os.listdir(CSRC)):
+        if src.endswith('.hip'):
+            n_src += 1
+            allp += ['store data hazard: ' + h for h in store_hazards(src)]
+    print(f'store-data / packed-fp32 hazard scan: {n_src} source files')
     for p in allp:
         print('VIOLATION:', p)
     return 1 if allp else 0
