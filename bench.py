@@ -257,6 +257,9 @@ def main():
                     help="N = 1: skip the two rocprofv3 --pmc passes that measure the dominant kernel's HBM traffic after the timed "
                          'region (roofline.traffic is then read from the newest committed summary and labelled so)')
     ap.add_argument('--layers', type=int, default=None, help='debug only: fewer layers (marks the line invalid)')
+    ap.add_argument('--gemm-variant', type=int, default=0,
+                    help='A/B only: force a tile schedule of mg_gemm_bf16 (same bits; 0 = the library default by shape, 8 = the round-3 '
+                         'default); recorded in config.gemm_variant')
     args = ap.parse_args()
     if args.transport is not None:        # read by wan.distributed at exchange-construction time; inherited by self-launched ranks
         os.environ['MOVIIGEN_SP_TRANSPORT'] = '' if args.transport == 'torch' else args.transport
@@ -302,6 +305,9 @@ def main():
     lat_shape = (16, (frames - 1) // 4 + 1, Hd // 8, Wd // 8)
     L = lat_shape[1] * (lat_shape[2] // 2) * (lat_shape[3] // 2)
 
+    if args.gemm_variant:
+        from wan.backend import lib as _lib
+        _lib.load().mg_gemm_set_variant(args.gemm_variant)
     model = wan.modules.WanModel(**cfg, device=dev)
     model.init_weights(seed=0)
     model.eval().requires_grad_(False)
@@ -476,7 +482,8 @@ def main():
             'config': {'workload': desc, 'latent': list(lat_shape), 'tokens': L, 'layers': cfg['num_layers'],
                        'parallelism': ('single' if world == 1 else f'cfg2 x ulysses_sp{sp}' if cfgp is not None else f'ulysses_sp{sp}')
                                       + (f' x fsdp{world}' if args.dit_fsdp and world > 1 else ''), 'solver': 'unipc',
-                       'guide_scale': 5.0, 'weights': 'random N(0,0.02) bf16, seed 0'},
+                       'guide_scale': 5.0, 'weights': 'random N(0,0.02) bf16, seed 0',
+                       **({'gemm_variant': args.gemm_variant} if args.gemm_variant else {})},
             'sec_per_video': (ms_step * 50 / 1e3 + vae_s) if vae_s is not None else None,
             'sec_per_video_parts': {'denoise_50_steps_s': ms_step * 50 / 1e3, 'vae_decode_s': vae_s,
                                     't5_encode_2_prompts_s_not_included': t5_s,

@@ -367,7 +367,9 @@ int mg_vae_time_interleave_f32(const float* x, int T, int64_t HW, int C, float* 
  * 11 = 256x256x64 tile, v_mfma_f32_16x16x32_bf16, persistent loop, 4 waves = ONE per SIMD (128x128 each); the k-tile is a
  *     GENERATED instruction schedule (tools/gen_gemm_v11_schedule.py): buffer_load ... lds with one 32-bit offset per piece,
  *     at most one other instruction behind each MFMA, counted lgkmcnt waits, the last 32 MFMAs of a k-tile behind the next
- *     k-tile's barrier; two schedules by K (110 + flags selects it with its experiment flags);
+ *     k-tile's barrier; two schedules by K; bf16 outputs stored 16 bytes per lane (W rows permuted in LDS), fp32 outputs
+ *     transposed through LDS and written / read-modified as whole row segments (110 + flags selects it with its experiment
+ *     flags: 1 de-phased waves, 2 raster 0, 4 no stores, 8 skewed start, 16 direct fp32 epilogue);
  * 8 = (the round-3 default, A/B partner) 256x256x64 tile, v_mfma_f32_16x16x32_bf16, persistent loop (one workgroup per CU; the first k-tile of the next
  *     tile is fetched during the last k-tile of the current one), EIGHT waves in two ping-pong groups: in every interval
  *     between two barriers one group issues 16 MFMAs per wave while its SIMD partners read fragments and issue LDS-DMA;

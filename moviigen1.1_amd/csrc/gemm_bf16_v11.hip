@@ -11,8 +11,12 @@
 //   * the LDS-DMA loads are BUFFER loads (`buffer_load_dwordx4 v_off, s[rsrc], s_koff offen lds`): one 32-bit VGPR offset per
 //     piece, set once per output tile (rows clamped there), the k advance in a scalar offset, the tile's base row in the
 //     resource — no 64-bit per-lane pointers, no VALU address arithmetic and no s_nop in the loop.
-// LDS image, XOR swizzle (on the source offset), fragment addressing, MFMA roles and order, epilogue and tile raster are variant
-// 7's: same arithmetic and accumulation order — identical bits (test_gemm_tile_variants_agree).
+//   * epilogues shaped for the CU's memory pipe, which takes one request per LANE when adjacent lanes are different output rows
+//     (experiments/store_probe.hip): the bf16 outputs store 16 bytes per lane (W rows staged in a permuted order, v11_epilogue_pair),
+//     the fp32 outputs go through LDS and out as whole row segments, the residual read the same way (v11_epilogue_rows).
+// LDS image, XOR swizzle (on the source offset), fragment addressing, MFMA roles and order and tile raster are variant 7's, the
+// epilogue arithmetic is gemm_epilogue.h's element for element: same accumulation order, identical bits
+// (test_gemm_tile_variants_agree, test_gemm_default_epilogues_match_direct_ones).
 #include "common.h"
 #include "gemm_epilogue.h"
 #include "../../include/moviigen_hip.h"
@@ -247,7 +251,7 @@ MG_DEV void v11_epilogue_rows(const f32x4_t (&acc)[8][8], char* __restrict__ sp,
 
 extern unsigned long long* g_gemm5_prof;    // gemm_bf16.hip: mg_gemm5_debug_profile
 
-// SCHED = gap stride of the LDS-DMA loads in the generated k-tile (6: K <= 8192, 4: K > 8192; tools/gen_gemm_v11_schedule.py)
+// SCHED = gap stride of the LDS-DMA loads in the generated k-tile (tools/gen_gemm_v11_schedule.py; chosen in the launcher)
 template <int EPI, int SCHED, bool PROF = false>
 __global__ __launch_bounds__(V11_THREADS, 1) void gemm_bf16_v11_kernel(
     const uint16_t* __restrict__ A, int64_t lda, const uint16_t* __restrict__ Wt, int64_t ldw,
@@ -450,7 +454,7 @@ __global__ __launch_bounds__(V11_THREADS, 1) void gemm_bf16_v11_kernel(
 int mg_gemm_v8_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_t ldw, const float* bias, int64_t M, int N, int K,
                       int epilogue, void* out, int64_t ldo, const float* gate, hipStream_t st);      // gemm_bf16_v8.hip
 
-static int g_v11_flags = 0;     // measurement bits (mg_gemm_set_variant(110 + flags)): 1 = de-phase the waves, 2 = raster 0 always, 4 = no stores (timing only), 8 = skewed start, 16 = fp32 outputs: direct epilogue
+static int g_v11_flags = 0;     // measurement bits (mg_gemm_set_variant(110 + flags)): 1 = de-phase the waves, 2 = raster 0 always, 4 = no stores (timing only), 8 = skewed start, 16 = fp32 outputs: direct epilogue, 32 = the every-4th-gap schedule whatever K
 void mg_gemm_v11_set_flags(int f) { g_v11_flags = f; }
 
 int mg_gemm_v11_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_t ldw, const float* bias, int64_t M,
@@ -474,8 +478,12 @@ int mg_gemm_v11_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64
     // raster by shape: variant 8's rule (profiles/r03r_gemm_rasters.log)
     const int raster = (nwg == 256 && tiles_n < 32 && !(g_v11_flags & 2)) ? (K > 8192 ? 1 : 3) : 0;
     const dim3 grid((unsigned)nwg), block(V11_THREADS);
+    // which generated k-tile: loads every 4th gap — K > 8192, and every shape on raster 0 (wide outputs: the XCDs stream different
+    // bands, the loads take longer to land; q|k|v 1332 vs 1281, ffn.0 1234 vs 1187 TFLOP/s, profiles/r04u_gemm_wide_s4.log) — or
+    // every 6th (the chip-wide rasters at K <= 8192: 2528 vs 2611 cycles per k-tile)
+    const bool sched4 = K > 8192 || raster == 0 || (g_v11_flags & 32);
     if (g_gemm5_prof && epilogue == MG_EPI_BIAS_BF16) {
-        if (K > 8192)
+        if (sched4)
             hipLaunchKernelGGL((gemm_bf16_v11_kernel<MG_EPI_BIAS_BF16, 4, true>), grid, block, 0, st, A, lda, Wt, ldw, bias, M, N, K, out, ldo, gate,
                                tiles_m, tiles_n, raster, g_v11_flags, g_gemm5_prof);
         else
@@ -485,7 +493,7 @@ int mg_gemm_v11_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64
     }
 #define LAUNCH(E)                                                                                                          \
     do {                                                                                                                   \
-        if (K > 8192)                                                                                                      \
+        if (sched4)                                                                                \
             hipLaunchKernelGGL((gemm_bf16_v11_kernel<E, 4, false>), grid, block, 0, st, A, lda, Wt, ldw, bias, M, N, K, out, ldo, \
                                gate, tiles_m, tiles_n, raster, g_v11_flags, nullptr);                                      \
         else                                                                                                               \

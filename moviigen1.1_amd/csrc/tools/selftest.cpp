@@ -709,6 +709,46 @@ int main(int argc, char** argv) {
         test_gemm(Mg, 5120, 13824, 2, 128, true);     // ffn.2 (+ gate, residual)
         return n_fail ? 1 : 0;
     }
+    if (argc > 1 && !strcmp(argv[1], "powerloop")) {   // powerloop gemm <variant> <secs> | attn 0 <secs>: ONE kernel back to back on random operands
+        // (tools/r04_gpu_w.sh samples rocm-smi power / clocks meanwhile: are the hot kernels at the power cap?)
+        const bool is_gemm = !strcmp(argv[2], "gemm");
+        const int var = atoi(argv[3]);
+        const double secs = argc > 4 ? atof(argv[4]) : 8.0;
+        const int64_t M = 131040;
+        auto blk = randbf((size_t)32 << 20);                 // 64 MiB of random bf16, tiled over the big operands
+        auto fill = [&](uint16_t* d, size_t n) {
+            for (size_t o = 0; o < n; o += blk.size())
+                CK(hipMemcpy(d + o, blk.data(), std::min(blk.size(), n - o) * 2, hipMemcpyHostToDevice));
+        };
+        double ms_sum = 0;
+        long launches = 0;
+        if (is_gemm) {
+            const int N = 5120, K = 5120;
+            Dev<uint16_t> dA((size_t)M * K), dW(randbf((size_t)N * K, 0.05f));
+            fill(dA.p, dA.n);
+            Dev<float> db(randf(N)), dg(randf(N)), of((size_t)M * N);
+            CK(hipMemset(of.p, 0, of.n * 4));
+            mg_gemm_set_variant(var);
+            while (ms_sum < secs * 1e3) {
+                ms_sum += 20 * time_ms([&] { mg_gemm_bf16(dA.p, K, dW.p, K, db.p, M, N, K, MG_EPI_GATE_RESID_F32, of.p, N, dg.p, 0); }, 20);
+                launches += 20;
+            }
+            printf("powerloop gemm variant %d: %ld launches, %.3f ms each = %.1f TFLOP/s\n", var, launches, ms_sum / launches,
+                   2.0 * M * N * K / (ms_sum / launches * 1e-3) / 1e12);
+        } else {
+            const int heads = 8;
+            const int64_t ld = heads * 128, npk = (int64_t)heads * ((M + 63) / 64) * 8192;
+            Dev<uint16_t> dq((size_t)M * ld), dkp((size_t)npk), dvp((size_t)npk), dout((size_t)M * ld);
+            fill(dq.p, dq.n); fill(dkp.p, dkp.n); fill(dvp.p, dvp.n);
+            while (ms_sum < secs * 1e3) {
+                ms_sum += 4 * time_ms([&] { mg_attn_fwd_bf16_hd128_prescaled(dq.p, ld, dkp.p, dvp.p, dout.p, ld, nullptr, M, M, heads, 0, 0); }, 4);
+                launches += 4;
+            }
+            printf("powerloop attention: %ld launches, %.3f ms each = %.1f TFLOP/s\n", launches, ms_sum / launches,
+                   4.0 * M * M * 128 * heads / (ms_sum / launches * 1e-3) / 1e12);
+        }
+        return 0;
+    }
     if (argc > 1 && !strcmp(argv[1], "gemmdiff")) {   // gemmdiff variant M N K epi: every element against variant 8, mismatches by position in the wave's block
         const int var = atoi(argv[2]);
         const int64_t M = atoll(argv[3]);
@@ -753,6 +793,12 @@ int main(int argc, char** argv) {
         gemm_ab(Mg, 5120, 13824, 2, vars, rounds);     // ffn.2 (+ gate, residual)
         gemm_ab(Mg, 5120, 5120, 0, vars, rounds);      // cross-attention q: store epilogue, the variants must tie
         printf("%s: %d failure(s)\n", n_fail ? "SELFTEST FAILED" : "SELFTEST OK", n_fail);
+        return n_fail ? 1 : 0;
+    }
+    if (argc > 1 && !strcmp(argv[1], "gemmab1")) {   // gemmab1 M N K epi rounds v1 v2 ...: one shape, variants alternating on one set of operands
+        std::vector<int> vars;
+        for (int i = 7; i < argc; ++i) vars.push_back(atoi(argv[i]));
+        gemm_ab(atoll(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), vars, atoi(argv[6]));
         return n_fail ? 1 : 0;
     }
     if (argc > 1 && !strcmp(argv[1], "gemmprof")) {  // s_memtime breakdown of the 256x128 GEMM k-loop

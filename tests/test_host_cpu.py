@@ -388,3 +388,26 @@ def test_hot_loops_static_audit():
         assert rep, k
         problems += prob
     assert not problems, problems
+
+
+def test_no_packed_write_behind_a_wide_store():
+    """every kernel of the library: no store of more than 64 bits directly followed by a packed-fp32 VALU instruction that overwrites
+    its data registers — hipcc leaves no wait state there for buffer stores with a scalar offset register, and on gfx950 the store
+    then picks up part of the new value in four lanes of every 16 (csrc/gemm_bf16_v11.hip)."""
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import audit_hot_loops
+    hits = []
+    for src in sorted(os.listdir(audit_hot_loops.CSRC)):
+        if src.endswith('.hip'):
+            hits += audit_hot_loops.store_hazards(src)
+    assert not hits, hits
+
+
+def test_gemm_v11_schedule_is_the_generators_output(tmp_path):
+    """the k-tile of GEMM variant 11 is generated code: the committed .inc files are what tools/gen_gemm_v11_schedule.py writes."""
+    env = dict(os.environ, MG_V11_GEN_DIR=str(tmp_path))
+    subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'gen_gemm_v11_schedule.py')], check=True, env=env, capture_output=True)
+    names = sorted(os.listdir(tmp_path))
+    assert names == ['gemm_bf16_v11_ktile_s4.inc', 'gemm_bf16_v11_ktile_s6.inc', 'gemm_bf16_v11_tail.inc']
+    for n in names:
+        assert open(os.path.join(tmp_path, n)).read() == open(os.path.join(ROOT, 'moviigen1.1_amd', 'csrc', n)).read(), n

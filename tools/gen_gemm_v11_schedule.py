@@ -144,7 +144,7 @@ if len(sys.argv) == 1:
 else:
     sections = [('ktile_s%d' % G_STRIDE, ktile(), G_STRIDE), ('tail', tail_only(), 0)]
 for name, sch, G_STRIDE in sections:
-    path = os.path.join(ROOT, 'moviigen1.1_amd', 'csrc', f'gemm_bf16_v11_{name}.inc')
+    path = os.path.join(os.environ.get('MG_V11_GEN_DIR', os.path.join(ROOT, 'moviigen1.1_amd', 'csrc')), f'gemm_bf16_v11_{name}.inc')
     with open(path, 'w') as f:
         f.write(f'// GENERATED by tools/gen_gemm_v11_schedule.py (TAIL_GROUPS = {TAIL_GROUPS}, G_STRIDE = {G_STRIDE}) — do not edit.\n'
                 f'// GEMM variant 11, section `{name}`: every non-MFMA instruction alone in the gap behind an MFMA, counted lgkmcnt waits.\n')
