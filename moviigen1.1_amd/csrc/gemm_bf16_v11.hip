@@ -341,7 +341,9 @@ __global__ __launch_bounds__(V11_THREADS, 1) void gemm_bf16_v11_kernel(
     // LDS byte address of piece p in stage s: lds0 + s * STAGE + prow0 * 128 + (p < 8 ? 0 : A_BYTES) + (p & 7) * 1024
     const unsigned lds_pieces = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + prow0 * 128));
 #define V11_PIECE_IMM(p) (((p) < 8 ? 0 : V11_A_BYTES) + ((p) & 7) * 1024)
-    {   // cold start of the FIRST tile only
+    {   // cold start of the FIRST tile only.  The resources were just written by v_readfirstlane and the loads are inline assembly: the
+        // compiler does not see a VMEM instruction reading those SGPRs (5 wait states) — keep the distance by hand.
+        asm volatile("s_nop 4" ::: "memory");
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 1" ::"s"(lds_pieces), "s"(V11_PIECE_IMM(i)) : "scc", "memory");
