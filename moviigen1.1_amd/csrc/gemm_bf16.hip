@@ -138,6 +138,8 @@ int mg_gemm_v7_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_
                       int N, int K, int epilogue, void* out, int64_t ldo, const float* gate, hipStream_t st);
 int mg_gemm_v8_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_t ldw, const float* bias, int64_t M,
                       int N, int K, int epilogue, void* out, int64_t ldo, const float* gate, hipStream_t st);
+int mg_gemm_v12_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_t ldw, const float* bias, int64_t M,
+                       int N, int K, int epilogue, void* out, int64_t ldo, const float* gate, hipStream_t st);       // gemm_bf16_v12.hip
 int mg_gemm_v11_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_t ldw, const float* bias, int64_t M,
                        int N, int K, int epilogue, void* out, int64_t ldo, const float* gate, hipStream_t st);
 int mg_gemm_v2_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_t ldw, const float* bias, int64_t M,
@@ -153,9 +155,11 @@ unsigned long long* g_gemm5_prof = nullptr;   // debug hook of the 256x256 kerne
 extern "C" void mg_gemm5_debug_profile(unsigned long long* dev_buf) { g_gemm5_prof = dev_buf; }
 static int g_gemm_variant = 0;   // 0 = by shape AND epilogue (below)
 void mg_gemm_v11_set_flags(int f);
-extern "C" void mg_gemm_set_variant(int v) {      // 110 + f: variant 11 with measurement flags f (gemm_bf16_v11.hip)
-    g_gemm_variant = v >= 110 ? 11 : v;
-    mg_gemm_v11_set_flags(v >= 110 ? v - 110 : 0);
+void mg_gemm_v12_set_flags(int f);
+extern "C" void mg_gemm_set_variant(int v) {      // 110 + f / 200 + f: variant 11 / 12 with measurement flags f (gemm_bf16_v11.hip, gemm_bf16_v12.hip)
+    g_gemm_variant = v >= 200 ? 12 : v >= 110 ? 11 : v;
+    mg_gemm_v11_set_flags(v >= 110 && v < 200 ? v - 110 : 0);
+    mg_gemm_v12_set_flags(v >= 200 ? v - 200 : 0);
 }
 
 extern "C" int mg_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_t ldw,
@@ -175,6 +179,8 @@ extern "C" int mg_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* Wt, 
     // one instruction per MFMA gap, the last MFMAs of a k-tile behind the next barrier): +1.4 ... +3.1 % over variant 8 on the five
     // shapes of a block at M = 131 040, identical bits (profiles/r04n_gemm_v11.log)
     const int variant = g_gemm_variant ? g_gemm_variant : 11;
+    if (variant == 12 && M > 256 && N > 128)
+        return mg_gemm_v12_launch(A, lda, Wt, ldw, bias, M, N, K, epilogue, out, ldo, gate, (hipStream_t)stream);
     if (variant == 11 && M > 256 && N > 128)
         return mg_gemm_v11_launch(A, lda, Wt, ldw, bias, M, N, K, epilogue, out, ldo, gate, (hipStream_t)stream);
     if (variant >= 8 && M > 256 && N > 128)

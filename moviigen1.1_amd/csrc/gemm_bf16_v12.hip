@@ -1,0 +1,286 @@
+// bf16 GEMM, variant 12: variant 11's tile, LDS image, fragment addressing, MFMA order, rasters and epilogues (gemm_v11_common.h) — identical
+// bits — on a k-loop in which a stage is REFILLED WHILE IT IS CONSUMED, for the k-tile two ahead.
+//
+// Why (profiles/r05a_pmc_lib_gemm.txt, one box, same operands): variant 11 needs 23-26 shader cycles per MFMA and SIMD, the vendor
+// library's assembly kernel of the same 256 x 256 x 64 tile 19.2; both run against the package-power limit (PPT residency 0.7,
+// profiles/r05a_telemetry.log), so the vendor kernel does the same work at 1.72 instead of 2.05 GHz — at a lower voltage — and finishes
+// 13 % earlier.  Variant 11's k-tile has one barrier behind `vmcnt(0)`: what a wave loads during k-tile t must have LANDED at the top of
+// k-tile t+1, so its 16 LDS-DMA loads are packed into the first half of the k-tile, among the fragment reads, and the barrier waits for the
+// stragglers.  With the same two 64 KiB stages a load can be given ~1.4 k-tiles instead:
+//   body of stream position g (stage s = g & 1; k-step-0 fragments already in registers)             tools/gen_gemm_v12_schedule.py
+//     64 MFMAs of k-step 0; in their gaps the 8 A-fragment reads of k-step 1, then
+//        BAR1 (lgkmcnt(0) + s_barrier): nobody reads stage s's A rows any more -> the wave's 8 A loads of k-tile g+2 go INTO stage s,
+//        between them the 8 W-fragment reads of k-step 1;  BAR2 (same): the W rows are free -> W loads of k-tile g+2
+//     64 MFMAs of k-step 1; more loads;  BAR3 (vmcnt(13) + s_barrier): k-tile g+1 — issued one body ago — has landed in stage s^1 -> its 16
+//        k-step-0 fragment reads, the last 3 loads.  No wait at the end: the next body's counted lgkmcnt waits follow the issue order.
+// Three barriers per k-tile, none behind a drained memory pipe.  The k-tile STREAM runs across output tiles: the body of a tile's last-but-one
+// k-tile loads the next tile's k-tile 0; the LAST k-tile of a tile is a body without loads, reads-ahead and barriers (gemm_bf16_v12_last.inc):
+// its stage is the fp32 epilogues' transposition buffer, and the registers of the fragments read ahead are the epilogue's.  Behind the
+// epilogue a short tile prologue issues the next tile's k-tile 1 and reads its k-step-0 fragments of k-tile 0 (landed: vmcnt(0) + barrier
+// closed the last body).  Needs K >= 128 (two k-tiles); the launcher sends anything else to variant 11.
+#include "gemm_v11_common.h"
+
+extern unsigned long long* g_gemm5_prof;    // gemm_bf16.hip: mg_gemm5_debug_profile
+
+template <int EPI, bool PROF = false>
+__global__ __launch_bounds__(V11_THREADS, 1) void gemm_bf16_v12_kernel(
+    const uint16_t* __restrict__ A, int64_t lda, const uint16_t* __restrict__ Wt, int64_t ldw,
+    const float* __restrict__ bias, int64_t M, int N, int K, void* __restrict__ out, int64_t ldo,
+    const float* __restrict__ gate, int tiles_m, int tiles_n, int raster, int flags, unsigned long long* __restrict__ prof) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * V11_STAGE];
+    unsigned long long pt[5] = {0, 0, 0, 0, 0}, ta = 0;                    // PROF: s_memtime {BAR1 wait, BAR2 wait, BAR3 wait, whole body, bodies}
+    unsigned long long pe[3] = {0, 0, 0};                                  // PROF: {whole kernel, last body's close + epilogue + tile prologue, tiles}
+    const unsigned long long t_start = PROF ? __builtin_amdgcn_s_memtime() : 0;
+
+    constexpr bool PAIRED = EPI == MG_EPI_BIAS_BF16 || EPI == MG_EPI_BIAS_GELU_BF16;
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int total = tiles_m * tiles_n;
+    // rasters: variant 11's (gemm_bf16_v11.hip)
+    const int q8 = total >> 3, r8 = total & 7, xcd = bid & 7;
+    const int xcd_first = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int xcd_count = q8 + (xcd < r8 ? 1 : 0);
+    const int per_iter = nwg >> 3;
+    const int XR = raster == 2 ? 8 : raster == 3 ? 2 : 4;
+    const int SR = 4 * XR;
+    const int GM = raster ? SR : 4;
+    const int per_group = GM * tiles_n;
+    const int slot = bid >> 3;
+    const int p256 = (8 * (xcd / XR) + (slot >> 2)) * SR + 4 * (xcd % XR) + (slot & 3);
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, r16 = lane & 15, G = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int srow = lane >> 3;
+    constexpr int NP = 16;                       // LDS-DMA duty: wave w stages rows [64w, 64w+64) of A (pieces 0-7) and of W (8-15)
+    const int prow0 = wave * 64;
+
+    auto tile_of = [&](int pos, int64_t& m0, int& n0) __attribute__((always_inline)) {
+        const int swz = raster ? pos * 256 + p256 : xcd_first + pos;
+        const int group = swz / per_group;
+        const int first_m = group * GM;
+        const int gsz = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
+        const int in_g = swz - group * per_group;
+        m0 = (int64_t)(first_m + in_g % gsz) * V11_BM;
+        n0 = (in_g / gsz) * V11_BN;
+    };
+    int voff[NP];
+    u32x4_t rs_a, rs_w;
+    auto set_offsets = [&](int64_t m0, int n0) __attribute__((always_inline)) {
+        const int64_t rows_a = M - m0;
+        const int rows_w = N - n0;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int row = prow0 + (i & 7) * 8 + srow;
+            const int chunk = ((lane & 7) ^ ((row >> 1) & 7)) << 4;
+            if (i < 8) {
+                const int r = row < rows_a ? row : (int)(rows_a - 1);
+                voff[i] = r * (int)(lda * 2) + chunk;
+            } else {
+                const int f = PAIRED ? v11_feature_of_row(row) : row;
+                const int r = f < rows_w ? f : rows_w - 1;
+                voff[i] = r * (int)(ldw * 2) + chunk;
+            }
+        }
+        rs_a = v11_rsrc(A + m0 * lda);
+        rs_w = v11_rsrc(Wt + (int64_t)n0 * ldw);
+    };
+
+    const int sw = (r16 >> 1) & 7;
+    const int t3 = G ^ sw;
+    const unsigned lds0 = (unsigned)(uintptr_t)(v11_lptr_t)smem;
+    // per-lane fragment addresses in stage 0: k-step 0 (chunk t3) and k-step 1 (chunk t3 ^ 4)
+    const unsigned pa0 = lds0 + (wm * 128 + r16) * 128 + (t3 << 4), pa1 = lds0 + (wm * 128 + r16) * 128 + ((t3 ^ 4) << 4);
+    const unsigned pw0 = lds0 + V11_A_BYTES + (wn * 128 + r16) * 128 + (t3 << 4), pw1 = lds0 + V11_A_BYTES + (wn * 128 + r16) * 128 + ((t3 ^ 4) << 4);
+    const int nk = K / V11_BK;                   // >= 2 (launcher)
+
+    int pos = raster ? 0 : bid >> 3;
+    if (raster ? p256 >= total : pos >= xcd_count) return;
+    int64_t m0;
+    int n0;
+    tile_of(pos, m0, n0);
+    set_offsets(m0, n0);
+    const unsigned lds_pieces = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + prow0 * 128));
+#define V12_PIECE_IMM(p) (((p) < 8 ? 0 : V11_A_BYTES) + ((p) & 7) * 1024)
+#define V12_SB __builtin_amdgcn_sched_barrier(0)
+    // 16 loads of one k-tile (byte offset kb along K) into the stage at lds_pieces + stage_off: outside the k-loop (kernel start, tile prologue)
+    auto cold_loads = [&](unsigned stage_off, int kb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 1" ::"s"(lds_pieces + stage_off), "s"(V12_PIECE_IMM(i)) : "scc", "memory");
+            v11_dma(voff[i], i < 8 ? rs_a : rs_w, kb);
+        }
+    };
+    bf16x8_t f0a[8], f0w[8], f1a[8], f1w[8];      // fragments of k-step 0 / 1
+    // the 16 k-step-0 fragment reads of the k-tile in stage `par`, in the order the bodies' counted waits assume (the generator's NEXT_ORDER)
+    auto read_first = [&](int par) __attribute__((always_inline)) {
+        const unsigned abn = pa0 + par * V11_STAGE, wbn = pw0 + par * V11_STAGE;
+        v11_rd<0>(f0w[0], wbn);
+        v11_rd<0>(f0a[0], abn);
+        v11_rd<2048>(f0a[1], abn);
+        v11_rd<4096>(f0a[2], abn);
+        v11_rd<6144>(f0a[3], abn);
+        v11_rd<2048>(f0w[1], wbn);
+        v11_rd<4096>(f0w[2], wbn);
+        v11_rd<6144>(f0w[3], wbn);
+        v11_rd<8192>(f0w[4], wbn);
+        v11_rd<10240>(f0w[5], wbn);
+        v11_rd<12288>(f0w[6], wbn);
+        v11_rd<14336>(f0w[7], wbn);
+        v11_rd<8192>(f0a[4], abn);
+        v11_rd<10240>(f0a[5], abn);
+        v11_rd<12288>(f0a[6], abn);
+        v11_rd<14336>(f0a[7], abn);
+    };
+    {   // kernel start: k-tiles 0 and 1 of the first tile -> stages 0 and 1.  The resources were just written by v_readfirstlane and the
+        // loads are inline assembly: keep the 5 wait states by hand (gemm_bf16_v11.hip).
+        asm volatile("s_nop 4" ::: "memory");
+        cold_loads(0, 0);
+        cold_loads(V11_STAGE, V11_BK * 2);
+        asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");        // k-tile 0 has landed, for every wave
+        V12_SB;
+        read_first(0);
+        // outside the k-loop the compiler may copy a fragment register on the way into the loop: let the reads return first
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        V12_SB;
+    }
+    int gk = 0;                                   // stream position: stage = gk & 1
+#define V12_TA if (PROF) ta = __builtin_amdgcn_s_memtime()
+#define V12_TB(k) if (PROF) pt[k] += __builtin_amdgcn_s_memtime() - ta
+#define V12_BAR_LGKM(k) do { V12_TA; asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); V12_TB(k - 1); } while (0)
+#define V12_BAR_VM(n) do { V12_TA; asm volatile("s_waitcnt vmcnt(" #n ")\n\ts_barrier" ::: "memory"); V12_TB(2); } while (0)
+    for (;;) {
+        f32x4_t acc[8][8];       // [feature block of 16][token block of 16]
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        const int next_pos = raster ? pos + 1 : pos + per_iter;
+        const bool has_next = raster ? next_pos * 256 + p256 < total : next_pos < xcd_count;
+        int64_t m0n = m0;
+        int n0n = n0;
+        for (int kt = 0; kt < nk - 1; ++kt, ++gk) {
+            const unsigned long long tq = PROF ? __builtin_amdgcn_s_memtime() : 0;
+            // what this body loads: stream element gk + 2 = k-tile kt + 2 of this tile, or — last-but-one k-tile — k-tile 0 of the NEXT tile
+            // (no next tile: a re-load of this very k-tile into its own stage, the same bytes)
+            int kb = (kt + 2) * (V11_BK * 2);
+            if (kt == nk - 2) {
+                kb = has_next ? 0 : kt * (V11_BK * 2);
+                if (has_next) {
+                    tile_of(next_pos, m0n, n0n);
+                    set_offsets(m0n, n0n);
+                }
+            }
+            const unsigned sb = (gk & 1) * V11_STAGE;
+            const unsigned lload = lds_pieces + sb;                                   // scalar: this wave's pieces of stream element gk + 2
+            const unsigned ab1 = pa1 + sb, wb1 = pw1 + sb;                            // k-step 1 of this k-tile
+            const unsigned abn = pa0 + (V11_STAGE - sb), wbn = pw0 + (V11_STAGE - sb);  // k-step 0 of the next one
+#define V12_M0(p) v11_set_m0<V12_PIECE_IMM(p)>(lload)
+#define V12_G(p) v11_dma(voff[p], (p) < 8 ? rs_a : rs_w, kb)
+            V12_SB;
+#include "gemm_bf16_v12_body.inc"
+#undef V12_G
+#undef V12_M0
+            // The MFMAs above are inline asm: the compiler's hazard recognizer does not know their results are still in the matrix pipe.
+            // Inside the loop nothing else touches an accumulator; on the loop's EXIT edge the register allocator renumbers accumulators
+            // for the last k-tile's code (v_accvgpr_mov right behind the last MFMA would read stale values): pad there (gemm_bf16_v11.hip).
+            if (kt == nk - 2) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+            if (PROF) pt[3] += __builtin_amdgcn_s_memtime() - tq, pt[4] += 1;
+        }
+        const unsigned long long te = PROF ? __builtin_amdgcn_s_memtime() : 0;
+        {   // the tile's last k-tile: MFMAs and the k-step-1 fragment reads only
+            const unsigned sb = (gk & 1) * V11_STAGE;
+            const unsigned ab1 = pa1 + sb, wb1 = pw1 + sb;
+            V12_SB;
+#include "gemm_bf16_v12_last.inc"
+            // (builtin MFMAs: the compiler orders the epilogue's accumulator reads behind them.)  Every load has landed — the next tile's
+            // k-tile 0 among them — and everyone is done reading this stage, the fp32 epilogues' transposition buffer.
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            V12_SB;
+            ++gk;
+        }
+        // ---- epilogue (gemm_v11_common.h) ----
+        if constexpr (PAIRED)
+            v11_epilogue_pair<EPI>(acc, m0 + wm * 128, n0 + wn * 128, r16, G, (flags & 4) ? 0 : M, N, bias, out, ldo);      // flags & 4: measurement without the stores
+        else {
+            const int64_t m_wave = m0 + wm * 128;
+            const int n_wave = n0 + wn * 128;
+            if (!(flags & 16) && m_wave + 128 <= M && n_wave + 128 <= N)      // the wave's whole 128 x 128 block exists (wave-uniform)
+                v11_epilogue_rows<EPI>(acc, smem + ((gk - 1) & 1) * V11_STAGE + wave * 16384, lane, r16, G, m_wave, n_wave, bias, gate, out, ldo);
+            else
+                mg_gemm_epilogue16<EPI, 8, 8>(acc, m_wave, n_wave, r16, G, (flags & 4) ? 0 : M, N, bias, gate, out, ldo);
+        }
+        if (!has_next) {
+            if (PROF) pe[1] += __builtin_amdgcn_s_memtime() - te, pe[2] += 1;
+            break;
+        }
+        pos = next_pos;
+        m0 = m0n;
+        n0 = n0n;
+        // ---- tile prologue: the next tile's k-tile 1 -> the stage the epilogue has just used; k-step-0 fragments of its k-tile 0 ----
+        if constexpr (!PAIRED) asm volatile("s_barrier" ::: "memory");      // the other waves' transposition slices overlap this wave's pieces
+        V12_SB;
+        cold_loads(((gk + 1) & 1) * V11_STAGE, V11_BK * 2);
+        V12_SB;
+        read_first(gk & 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        V12_SB;
+        if (PROF) pe[1] += __builtin_amdgcn_s_memtime() - te, pe[2] += 1;
+    }
+#undef V12_BAR_VM
+#undef V12_BAR_LGKM
+#undef V12_TB
+#undef V12_TA
+#undef V12_PIECE_IMM
+#undef V12_SB
+    if (PROF && lane == 0 && prof) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) atomicAdd(prof + wave * 5 + i, pt[i]);
+        pe[0] = __builtin_amdgcn_s_memtime() - t_start;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) atomicAdd(prof + 32 + wave * 3 + i, pe[i]);
+    }
+}
+
+int mg_gemm_v11_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_t ldw, const float* bias, int64_t M, int N, int K,
+                       int epilogue, void* out, int64_t ldo, const float* gate, hipStream_t st);      // gemm_bf16_v11.hip
+
+static int g_v12_flags = 0;     // measurement bits (mg_gemm_set_variant(120 + flags)): 2 = raster 0 always, 4 = no stores (timing only), 16 = fp32 outputs: direct epilogue
+void mg_gemm_v12_set_flags(int f) { g_v12_flags = f; }
+
+int mg_gemm_v12_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_t ldw, const float* bias, int64_t M,
+                       int N, int K, int epilogue, void* out, int64_t ldo, const float* gate, hipStream_t st) {
+    // one k-tile only, unaligned bf16 pitches, strides past the 32-bit tile offsets: variant 11's launcher decides (and falls back itself)
+    if (K < 2 * V11_BK || lda * 2 * 256 > 0x7fffffffLL || ldw * 2 * 256 > 0x7fffffffLL || ldo * 4 * 128 > 0x7fffffffLL ||
+        ((epilogue == MG_EPI_BIAS_BF16 || epilogue == MG_EPI_BIAS_GELU_BF16) && (ldo & 7)))
+        return mg_gemm_v11_launch(A, lda, Wt, ldw, bias, M, N, K, epilogue, out, ldo, gate, st);
+    int n_cu = mg_cu_count();
+    if (n_cu < 0) return MG_ERR_LAUNCH;
+    n_cu &= ~7;
+    if (n_cu < 8) n_cu = 8;
+    const int64_t tiles_m64 = (M + V11_BM - 1) / V11_BM;
+    const int tiles_n = (N + V11_BN - 1) / V11_BN;
+    if (tiles_m64 * tiles_n > 0x7fffffffLL) return MG_ERR_SHAPE;
+    const int tiles_m = (int)tiles_m64;
+    const int total = tiles_m * tiles_n;
+    int nwg = n_cu;
+    if (total < nwg) nwg = (total + 7) & ~7;
+    const int raster = (nwg == 256 && tiles_n < 32 && !(g_v12_flags & 2)) ? (K > 8192 ? 1 : 3) : 0;      // variant 8's rule
+    const dim3 grid((unsigned)nwg), block(V11_THREADS);
+    if (g_gemm5_prof && epilogue == MG_EPI_BIAS_BF16) {
+        hipLaunchKernelGGL((gemm_bf16_v12_kernel<MG_EPI_BIAS_BF16, true>), grid, block, 0, st, A, lda, Wt, ldw, bias, M, N, K, out, ldo, gate,
+                           tiles_m, tiles_n, raster, g_v12_flags, g_gemm5_prof);
+        return mg_check_launch();
+    }
+#define LAUNCH(E)                                                                                                                  \
+    hipLaunchKernelGGL((gemm_bf16_v12_kernel<E, false>), grid, block, 0, st, A, lda, Wt, ldw, bias, M, N, K, out, ldo, gate, tiles_m, \
+                       tiles_n, raster, g_v12_flags, nullptr)
+    switch (epilogue) {
+        case MG_EPI_BIAS_BF16: LAUNCH(MG_EPI_BIAS_BF16); break;
+        case MG_EPI_BIAS_GELU_BF16: LAUNCH(MG_EPI_BIAS_GELU_BF16); break;
+        case MG_EPI_GATE_RESID_F32: LAUNCH(MG_EPI_GATE_RESID_F32); break;
+        default: LAUNCH(MG_EPI_BIAS_F32); break;
+    }
+#undef LAUNCH
+    return mg_check_launch();
+}

@@ -811,7 +811,16 @@ int main(int argc, char** argv) {
         test_gemm(argc > 3 ? atoll(argv[3]) : 75600, argc > 4 ? atoi(argv[4]) : 5120, argc > 5 ? atoi(argv[5]) : 5120, 0, 64, true);
         unsigned long long h[64];
         CK(hipMemcpy(h, buf, sizeof h, hipMemcpyDeviceToHost));
-        if (gv == 11 || gv >= 110) {      // variant 11: 4 waves x {barrier, to the first MFMA, k-step 0, k-step 1, k-tiles}
+        if (gv == 12 || gv >= 200) {      // variant 12: 4 waves x {BAR1 wait, BAR2 wait, BAR3 wait, whole body, bodies}; the last k-tile of a tile is not a body
+            for (int w = 0; w < 4; ++w) {
+                const double n = (double)h[w * 5 + 4];
+                printf("wave %d: bodies %.0f  BAR1 wait %.0f  BAR2 wait %.0f  BAR3 wait %.0f  whole body %.0f (cycles per k-tile)\n", w, n,
+                       h[w * 5] / n, h[w * 5 + 1] / n, h[w * 5 + 2] / n, h[w * 5 + 3] / n);
+                const double tiles = (double)h[32 + w * 3 + 2], tot = (double)h[32 + w * 3], epi = (double)h[32 + w * 3 + 1];
+                printf("        per tile: %.0f cycles = bodies %.0f + last k-tile / epilogue / tile prologue %.0f + rest %.0f   (%.0f tiles)\n", tot / tiles,
+                       (double)h[w * 5 + 3] / tiles, epi / tiles, (tot - (double)h[w * 5 + 3] - epi) / tiles, tiles);
+            }
+        } else if (gv == 11 || gv >= 110) {      // variant 11: 4 waves x {barrier, to the first MFMA, k-step 0, k-step 1, k-tiles}
             for (int w = 0; w < 4; ++w) {
                 const double n = (double)h[w * 5 + 4];
                 printf("wave %d: k-tiles %.0f  vmcnt+barrier %.0f  to first MFMA %.0f  k-step 0 %.0f  k-step 1 %.0f  sum %.0f (cycles per k-tile)\n", w, n,
