@@ -22,13 +22,14 @@
 
 extern unsigned long long* g_gemm5_prof;    // gemm_bf16.hip: mg_gemm5_debug_profile
 
-template <int EPI, bool PROF = false>
+// SCHED = which generated body (tools/gen_gemm_v12_schedule.py: SCHEDULES); chosen in the launcher
+template <int EPI, int SCHED, bool PROF = false>
 __global__ __launch_bounds__(V11_THREADS, 1) void gemm_bf16_v12_kernel(
     const uint16_t* __restrict__ A, int64_t lda, const uint16_t* __restrict__ Wt, int64_t ldw,
     const float* __restrict__ bias, int64_t M, int N, int K, void* __restrict__ out, int64_t ldo,
     const float* __restrict__ gate, int tiles_m, int tiles_n, int raster, int flags, unsigned long long* __restrict__ prof) {
     __shared__ __attribute__((aligned(16))) char smem[2 * V11_STAGE];
-    unsigned long long pt[5] = {0, 0, 0, 0, 0}, ta = 0;                    // PROF: s_memtime {BAR1 wait, BAR2 wait, BAR3 wait, whole body, bodies}
+    unsigned long long pt[5] = {0, 0, 0, 0, 0}, ta = 0;                    // PROF: s_memtime {wait at the lgkmcnt barriers, -, wait at the vmcnt barrier, whole body, bodies}
     unsigned long long pe[3] = {0, 0, 0};                                  // PROF: {whole kernel, last body's close + epilogue + tile prologue, tiles}
     const unsigned long long t_start = PROF ? __builtin_amdgcn_s_memtime() : 0;
 
@@ -103,18 +104,17 @@ __global__ __launch_bounds__(V11_THREADS, 1) void gemm_bf16_v12_kernel(
     const unsigned lds_pieces = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + prow0 * 128));
 #define V12_PIECE_IMM(p) (((p) < 8 ? 0 : V11_A_BYTES) + ((p) & 7) * 1024)
 #define V12_SB __builtin_amdgcn_sched_barrier(0)
-    // 16 loads of one k-tile (byte offset kb along K) into the stage at lds_pieces + stage_off: outside the k-loop (kernel start, tile prologue)
-    auto cold_loads = [&](unsigned stage_off, int kb) __attribute__((always_inline)) {
+    // 16 loads of one k-tile (byte offset kb along K) to the pieces at `base` (scalar): outside the k-loop (kernel start, tile prologue)
+    auto cold_loads = [&](unsigned base, int kb) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
-            asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 1" ::"s"(lds_pieces + stage_off), "s"(V12_PIECE_IMM(i)) : "scc", "memory");
+            asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 1" ::"s"(base), "s"(V12_PIECE_IMM(i)) : "scc", "memory");
             v11_dma(voff[i], i < 8 ? rs_a : rs_w, kb);
         }
     };
     bf16x8_t f0a[8], f0w[8], f1a[8], f1w[8];      // fragments of k-step 0 / 1
-    // the 16 k-step-0 fragment reads of the k-tile in stage `par`, in the order the bodies' counted waits assume (the generator's NEXT_ORDER)
-    auto read_first = [&](int par) __attribute__((always_inline)) {
-        const unsigned abn = pa0 + par * V11_STAGE, wbn = pw0 + par * V11_STAGE;
+    // the 16 k-step-0 fragment reads of a k-tile, in the order the bodies' counted waits assume (the generator's NEXT_ORDER)
+    auto read_first = [&](unsigned abn, unsigned wbn) __attribute__((always_inline)) {
         v11_rd<0>(f0w[0], wbn);
         v11_rd<0>(f0a[0], abn);
         v11_rd<2048>(f0a[1], abn);
@@ -131,24 +131,42 @@ __global__ __launch_bounds__(V11_THREADS, 1) void gemm_bf16_v12_kernel(
         v11_rd<10240>(f0a[5], abn);
         v11_rd<12288>(f0a[6], abn);
         v11_rd<14336>(f0a[7], abn);
+        // outside the k-loop the compiler may copy a fragment register on the way into the loop: let the reads return first
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
+    // The stage toggles below are XORs with the stage size: the two stages must be one naturally aligned 128 KiB block (the kernel's only
+    // LDS object sits at LDS address 0).
+    if (lds0 & (2 * V11_STAGE - 1)) __builtin_trap();
     {   // kernel start: k-tiles 0 and 1 of the first tile -> stages 0 and 1.  The resources were just written by v_readfirstlane and the
         // loads are inline assembly: keep the 5 wait states by hand (gemm_bf16_v11.hip).
         asm volatile("s_nop 4" ::: "memory");
-        cold_loads(0, 0);
-        cold_loads(V11_STAGE, V11_BK * 2);
+        cold_loads(lds_pieces, 0);
+        cold_loads(lds_pieces + V11_STAGE, V11_BK * 2);
         asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");        // k-tile 0 has landed, for every wave
         V12_SB;
-        read_first(0);
-        // outside the k-loop the compiler may copy a fragment register on the way into the loop: let the reads return first
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        read_first(pa0, pw0);
         V12_SB;
     }
-    int gk = 0;                                   // stream position: stage = gk & 1
+    // Loop-carried state of the k-tile stream, ADVANCED INSIDE THE BODY by pinned one-instruction statements in MFMA gaps (V12_X_*, placed by
+    // the generator behind each one's last use) — computed by the compiler at the top of the body they were ~10 instructions per k-tile with
+    // the matrix pipe empty, and a body whose loop control grew by another dozen ran 7 % slower (profiles/r05i_gemm_v12_cont.log):
+    unsigned ab1 = pa1, wb1 = pw1;                                  // k-step-1 fragment addresses in the stage being consumed
+    unsigned abn = pa0 + V11_STAGE, wbn = pw0 + V11_STAGE;          // k-step-0 fragment addresses in the other stage (the next k-tile)
+    unsigned lload = lds_pieces;                                    // scalar: this wave's pieces in the stage being consumed (refilled for k-tile + 2)
+    int kb = 2 * (V11_BK * 2);                                      // scalar: byte offset along K of what the body loads
+#define V12_X_ab1 asm volatile("v_xor_b32 %0, 0x10000, %0" : "+v"(ab1))
+#define V12_X_wb1 asm volatile("v_xor_b32 %0, 0x10000, %0" : "+v"(wb1))
+#define V12_X_abn asm volatile("v_xor_b32 %0, 0x10000, %0" : "+v"(abn))
+#define V12_X_wbn asm volatile("v_xor_b32 %0, 0x10000, %0" : "+v"(wbn))
+#define V12_X_lload asm volatile("s_xor_b32 %0, %0, 0x10000" : "+s"(lload) : : "scc")
+#define V12_X_kb asm volatile("s_add_u32 %0, %0, 0x80" : "+s"(kb) : : "scc")
+    static_assert(V11_STAGE == 0x10000 && V11_BK * 2 == 0x80, "the literals above");
 #define V12_TA if (PROF) ta = __builtin_amdgcn_s_memtime()
 #define V12_TB(k) if (PROF) pt[k] += __builtin_amdgcn_s_memtime() - ta
-#define V12_BAR_LGKM(k) do { V12_TA; asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); V12_TB(k - 1); } while (0)
+#define V12_BAR_LGKM do { V12_TA; asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); V12_TB(0); } while (0)
 #define V12_BAR_VM(n) do { V12_TA; asm volatile("s_waitcnt vmcnt(" #n ")\n\ts_barrier" ::: "memory"); V12_TB(2); } while (0)
+#define V12_M0(p) v11_set_m0<V12_PIECE_IMM(p)>(lload)
+#define V12_G(p) v11_dma(voff[p], (p) < 8 ? rs_a : rs_w, kb)
     for (;;) {
         f32x4_t acc[8][8];       // [feature block of 16][token block of 16]
 #pragma unroll
@@ -159,46 +177,50 @@ __global__ __launch_bounds__(V11_THREADS, 1) void gemm_bf16_v12_kernel(
         const bool has_next = raster ? next_pos * 256 + p256 < total : next_pos < xcd_count;
         int64_t m0n = m0;
         int n0n = n0;
-        for (int kt = 0; kt < nk - 1; ++kt, ++gk) {
-            const unsigned long long tq = PROF ? __builtin_amdgcn_s_memtime() : 0;
-            // what this body loads: stream element gk + 2 = k-tile kt + 2 of this tile, or — last-but-one k-tile — k-tile 0 of the NEXT tile
-            // (no next tile: a re-load of this very k-tile into its own stage, the same bytes)
-            int kb = (kt + 2) * (V11_BK * 2);
-            if (kt == nk - 2) {
-                kb = has_next ? 0 : kt * (V11_BK * 2);
+        // The tile's nk - 1 full bodies run as TWO passes through ONE copy of the body: nk - 2 bodies that load this tile's own k-tiles
+        // (kb advances by one k-tile per body, inside the body), then — the offsets switched to the NEXT tile — one body that loads its
+        // k-tile 0 (no next tile: a re-load of this very k-tile into its own stage, the same bytes).  Written as a conditional inside a single
+        // loop, the switch cost every k-tile a vector compare, two branches and eight scalar moves (the resources' phi copies); as a second
+        // textual copy of the body, the register allocator numbers the accumulators differently in each copy and moves them in between.
+        int n_bodies = nk - 2, passes = 2;
+        asm volatile("" : "+s"(passes));      // opaque: two passes through one loop, not two loops
+#pragma nounroll
+        for (int pass = 0; pass < passes; ++pass) {
+#pragma nounroll
+            for (int i = 0; i < n_bodies; ++i) {
+                const unsigned long long tq = PROF ? __builtin_amdgcn_s_memtime() : 0;
+                V12_SB;
+                if constexpr (SCHED == 0) {
+#include "gemm_bf16_v12_body_s0.inc"
+                } else {
+#include "gemm_bf16_v12_body_s2.inc"
+                }
+                if (PROF) pt[3] += __builtin_amdgcn_s_memtime() - tq, pt[4] += 1;
+            }
+            if (pass == 0) {
+                kb = has_next ? 0 : (nk - 2) * (V11_BK * 2);
                 if (has_next) {
                     tile_of(next_pos, m0n, n0n);
                     set_offsets(m0n, n0n);
                 }
+                n_bodies = 1;
             }
-            const unsigned sb = (gk & 1) * V11_STAGE;
-            const unsigned lload = lds_pieces + sb;                                   // scalar: this wave's pieces of stream element gk + 2
-            const unsigned ab1 = pa1 + sb, wb1 = pw1 + sb;                            // k-step 1 of this k-tile
-            const unsigned abn = pa0 + (V11_STAGE - sb), wbn = pw0 + (V11_STAGE - sb);  // k-step 0 of the next one
-#define V12_M0(p) v11_set_m0<V12_PIECE_IMM(p)>(lload)
-#define V12_G(p) v11_dma(voff[p], (p) < 8 ? rs_a : rs_w, kb)
-            V12_SB;
-#include "gemm_bf16_v12_body.inc"
-#undef V12_G
-#undef V12_M0
-            // The MFMAs above are inline asm: the compiler's hazard recognizer does not know their results are still in the matrix pipe.
-            // Inside the loop nothing else touches an accumulator; on the loop's EXIT edge the register allocator renumbers accumulators
-            // for the last k-tile's code (v_accvgpr_mov right behind the last MFMA would read stale values): pad there (gemm_bf16_v11.hip).
-            if (kt == nk - 2) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-            if (PROF) pt[3] += __builtin_amdgcn_s_memtime() - tq, pt[4] += 1;
         }
+        // The MFMAs above are inline asm: the compiler's hazard recognizer does not know their results are still in the matrix pipe.  Inside
+        // the loop nothing else touches an accumulator; behind it the epilogue reads them, and the register allocator may renumber them for the
+        // last k-tile's code copy: pad first.  (tools/audit_hot_loops.py checks that no accumulator instruction stands between the loop's last
+        // MFMA and this pad.)
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+        V12_SB;
         const unsigned long long te = PROF ? __builtin_amdgcn_s_memtime() : 0;
-        {   // the tile's last k-tile: MFMAs and the k-step-1 fragment reads only
-            const unsigned sb = (gk & 1) * V11_STAGE;
-            const unsigned ab1 = pa1 + sb, wb1 = pw1 + sb;
-            V12_SB;
+        // the tile's last k-tile: MFMAs and the k-step-1 fragment reads only
+        const unsigned stage_last = lload - lds_pieces;
+        V12_SB;
 #include "gemm_bf16_v12_last.inc"
-            // (builtin MFMAs: the compiler orders the epilogue's accumulator reads behind them.)  Every load has landed — the next tile's
-            // k-tile 0 among them — and everyone is done reading this stage, the fp32 epilogues' transposition buffer.
-            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-            V12_SB;
-            ++gk;
-        }
+        // (builtin MFMAs: the compiler orders the epilogue's accumulator reads behind them.)  Every load has landed — the next tile's
+        // k-tile 0 among them — and everyone is done reading this stage, the fp32 epilogues' transposition buffer.
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        V12_SB;
         // ---- epilogue (gemm_v11_common.h) ----
         if constexpr (PAIRED)
             v11_epilogue_pair<EPI>(acc, m0 + wm * 128, n0 + wn * 128, r16, G, (flags & 4) ? 0 : M, N, bias, out, ldo);      // flags & 4: measurement without the stores
@@ -206,7 +228,7 @@ __global__ __launch_bounds__(V11_THREADS, 1) void gemm_bf16_v12_kernel(
             const int64_t m_wave = m0 + wm * 128;
             const int n_wave = n0 + wn * 128;
             if (!(flags & 16) && m_wave + 128 <= M && n_wave + 128 <= N)      // the wave's whole 128 x 128 block exists (wave-uniform)
-                v11_epilogue_rows<EPI>(acc, smem + ((gk - 1) & 1) * V11_STAGE + wave * 16384, lane, r16, G, m_wave, n_wave, bias, gate, out, ldo);
+                v11_epilogue_rows<EPI>(acc, smem + stage_last + wave * 16384, lane, r16, G, m_wave, n_wave, bias, gate, out, ldo);
             else
                 mg_gemm_epilogue16<EPI, 8, 8>(acc, m_wave, n_wave, r16, G, (flags & 4) ? 0 : M, N, bias, gate, out, ldo);
         }
@@ -217,20 +239,31 @@ __global__ __launch_bounds__(V11_THREADS, 1) void gemm_bf16_v12_kernel(
         pos = next_pos;
         m0 = m0n;
         n0 = n0n;
-        // ---- tile prologue: the next tile's k-tile 1 -> the stage the epilogue has just used; k-step-0 fragments of its k-tile 0 ----
+        // ---- tile prologue: the next tile's k-tile 1 -> the stage the last k-tile was read from (and the fp32 epilogue has used); the
+        // k-step-0 fragments of its k-tile 0 (landed: vmcnt(0) + barrier above); then the state steps over the last k-tile ----
         if constexpr (!PAIRED) asm volatile("s_barrier" ::: "memory");      // the other waves' transposition slices overlap this wave's pieces
         V12_SB;
-        cold_loads(((gk + 1) & 1) * V11_STAGE, V11_BK * 2);
+        cold_loads(lload, V11_BK * 2);
         V12_SB;
-        read_first(gk & 1);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        read_first(abn, wbn);
         V12_SB;
+        V12_X_ab1; V12_X_wb1; V12_X_abn; V12_X_wbn; V12_X_lload;
+        kb = 2 * (V11_BK * 2);
         if (PROF) pe[1] += __builtin_amdgcn_s_memtime() - te, pe[2] += 1;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no LDS-DMA load may still be on its way when the workgroup's LDS is released
+#undef V12_G
+#undef V12_M0
 #undef V12_BAR_VM
 #undef V12_BAR_LGKM
 #undef V12_TB
 #undef V12_TA
+#undef V12_X_kb
+#undef V12_X_lload
+#undef V12_X_wbn
+#undef V12_X_abn
+#undef V12_X_wb1
+#undef V12_X_ab1
 #undef V12_PIECE_IMM
 #undef V12_SB
     if (PROF && lane == 0 && prof) {
@@ -245,7 +278,7 @@ __global__ __launch_bounds__(V11_THREADS, 1) void gemm_bf16_v12_kernel(
 int mg_gemm_v11_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_t ldw, const float* bias, int64_t M, int N, int K,
                        int epilogue, void* out, int64_t ldo, const float* gate, hipStream_t st);      // gemm_bf16_v11.hip
 
-static int g_v12_flags = 0;     // measurement bits (mg_gemm_set_variant(120 + flags)): 2 = raster 0 always, 4 = no stores (timing only), 16 = fp32 outputs: direct epilogue
+static int g_v12_flags = 0;     // measurement bits (mg_gemm_set_variant(200 + flags)): 2 = raster 0 always, 4 = no stores (timing only), 16 = fp32 outputs: direct epilogue, 32 * (1 + s) = generated body s (0 / 2)
 void mg_gemm_v12_set_flags(int f) { g_v12_flags = f; }
 
 int mg_gemm_v12_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_t ldw, const float* bias, int64_t M,
@@ -267,14 +300,17 @@ int mg_gemm_v12_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64
     if (total < nwg) nwg = (total + 7) & ~7;
     const int raster = (nwg == 256 && tiles_n < 32 && !(g_v12_flags & 2)) ? (K > 8192 ? 1 : 3) : 0;      // variant 8's rule
     const dim3 grid((unsigned)nwg), block(V11_THREADS);
+    // which generated body: measurement override in bits 5-7 of the flags (mg_gemm_set_variant(200 + 32 * (1 + s))), else body 0 (the six
+    // bodies tried differ by < 1 %, profiles/r05c / r05g / r05h_gemm_v12_sched.log)
+    const int sched = (g_v12_flags >> 5) == 3 ? 2 : 0;
+#define LAUNCH_S(E, S, P)                                                                                                                \
+    hipLaunchKernelGGL((gemm_bf16_v12_kernel<E, S, P>), grid, block, 0, st, A, lda, Wt, ldw, bias, M, N, K, out, ldo, gate, tiles_m, tiles_n, \
+                       raster, g_v12_flags & 31, P ? g_gemm5_prof : nullptr)
+#define LAUNCH(E) do { if (sched == 2) LAUNCH_S(E, 2, false); else LAUNCH_S(E, 0, false); } while (0)
     if (g_gemm5_prof && epilogue == MG_EPI_BIAS_BF16) {
-        hipLaunchKernelGGL((gemm_bf16_v12_kernel<MG_EPI_BIAS_BF16, true>), grid, block, 0, st, A, lda, Wt, ldw, bias, M, N, K, out, ldo, gate,
-                           tiles_m, tiles_n, raster, g_v12_flags, g_gemm5_prof);
+        LAUNCH_S(MG_EPI_BIAS_BF16, 0, true);
         return mg_check_launch();
     }
-#define LAUNCH(E)                                                                                                                  \
-    hipLaunchKernelGGL((gemm_bf16_v12_kernel<E, false>), grid, block, 0, st, A, lda, Wt, ldw, bias, M, N, K, out, ldo, gate, tiles_m, \
-                       tiles_n, raster, g_v12_flags, nullptr)
     switch (epilogue) {
         case MG_EPI_BIAS_BF16: LAUNCH(MG_EPI_BIAS_BF16); break;
         case MG_EPI_BIAS_GELU_BF16: LAUNCH(MG_EPI_BIAS_GELU_BF16); break;
@@ -282,5 +318,6 @@ int mg_gemm_v12_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64
         default: LAUNCH(MG_EPI_BIAS_F32); break;
     }
 #undef LAUNCH
+#undef LAUNCH_S
     return mg_check_launch();
 }

@@ -63,22 +63,32 @@ template <int EPI, bool FULL, bool FULLM>
 MG_DEV void v11_epilogue_pair_impl(const f32x4_t (&acc)[8][8], int64_t m_wave, int n_wave, int r16, int G, int64_t M, int N,
                                    const float* __restrict__ bias, void* __restrict__ out, int64_t ldo) {
     static_assert(EPI == MG_EPI_BIAS_BF16 || EPI == MG_EPI_BIAS_GELU_BF16, "bf16 outputs only");
+    // the four bias octets of the lane first, as ONE batch of loads: inside the loop below each of them was a separate round trip to the L2
+    // with the matrix pipe idle (4 x ~0.5 us per tile)
+    // (one opaque asm statement consumes all eight vectors: without it hipcc sinks each load to its first use, gemm_epilogue.h)
+    f32x4_t b4a[4][2];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int n = n_wave + p * 32 + G * 8;
+        b4a[p][0] = b4a[p][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        if (bias && (FULL || n < N)) {
+            if (FULL || n + 7 < N) {
+                b4a[p][0] = *(const f32x4_t*)(bias + n);
+                b4a[p][1] = *(const f32x4_t*)(bias + n + 4);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (n + e < N) b4a[p][e >> 2][e & 3] = bias[n + e];
+            }
+        }
+    }
+    asm volatile("" : "+v"(b4a[0][0]), "+v"(b4a[0][1]), "+v"(b4a[1][0]), "+v"(b4a[1][1]), "+v"(b4a[2][0]), "+v"(b4a[2][1]), "+v"(b4a[3][0]), "+v"(b4a[3][1]));
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int n = n_wave + p * 32 + G * 8;
         if (!FULL && n >= N) continue;
         const bool full = FULL || n + 7 < N;
-        float b8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (bias) {
-            if (full) {
-                *(float4*)&b8[0] = *(const float4*)(bias + n);
-                *(float4*)&b8[4] = *(const float4*)(bias + n + 4);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    if (n + e < N) b8[e] = bias[n + e];
-            }
-        }
+        const float b8[8] = {b4a[p][0][0], b4a[p][0][1], b4a[p][0][2], b4a[p][0][3], b4a[p][1][0], b4a[p][1][1], b4a[p][1][2], b4a[p][1][3]};
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int64_t m = m_wave + j * 16 + r16;

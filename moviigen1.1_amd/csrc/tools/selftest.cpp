@@ -814,8 +814,8 @@ int main(int argc, char** argv) {
         if (gv == 12 || gv >= 200) {      // variant 12: 4 waves x {BAR1 wait, BAR2 wait, BAR3 wait, whole body, bodies}; the last k-tile of a tile is not a body
             for (int w = 0; w < 4; ++w) {
                 const double n = (double)h[w * 5 + 4];
-                printf("wave %d: bodies %.0f  BAR1 wait %.0f  BAR2 wait %.0f  BAR3 wait %.0f  whole body %.0f (cycles per k-tile)\n", w, n,
-                       h[w * 5] / n, h[w * 5 + 1] / n, h[w * 5 + 2] / n, h[w * 5 + 3] / n);
+                printf("wave %d: bodies %.0f  wait at the lgkmcnt barriers %.0f  at the vmcnt barrier %.0f  whole body %.0f (cycles per k-tile)\n", w, n,
+                       h[w * 5] / n, h[w * 5 + 2] / n, h[w * 5 + 3] / n);
                 const double tiles = (double)h[32 + w * 3 + 2], tot = (double)h[32 + w * 3], epi = (double)h[32 + w * 3 + 1];
                 printf("        per tile: %.0f cycles = bodies %.0f + last k-tile / epilogue / tile prologue %.0f + rest %.0f   (%.0f tiles)\n", tot / tiles,
                        (double)h[w * 5 + 3] / tiles, epi / tiles, (tot - (double)h[w * 5 + 3] - epi) / tiles, tiles);

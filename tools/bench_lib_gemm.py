@@ -13,7 +13,11 @@ for p in (ROOT, os.path.join(ROOT, 'moviigen1.1_amd')):
 import torch  # noqa: E402
 from wan.backend import ops  # noqa: E402
 
+from wan.backend import lib as _lib  # noqa: E402
+
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 131040
+if os.environ.get('MG_GEMM_VARIANT'):       # measurement only: 0 = the library's own choice by shape
+    _lib.load().mg_gemm_set_variant(int(os.environ['MG_GEMM_VARIANT']))
 dev = torch.device('cuda:0')
 g = torch.Generator(device=dev).manual_seed(0)
 
@@ -30,7 +34,10 @@ def timed(fn, iters=5):
     return a.elapsed_time(b) / iters
 
 
-for (N, K, name) in ((15360, 5120, 'q|k|v'), (5120, 5120, 'cross q'), (13824, 5120, 'ffn.0 (bias only)'), (5120, 13824, 'ffn.2 (bias only)')):
+SHAPES = ((15360, 5120, 'q|k|v'), (5120, 5120, 'cross q'), (13824, 5120, 'ffn.0 (bias only)'), (5120, 13824, 'ffn.2 (bias only)'))
+if os.environ.get('MG_LIB_GEMM_SHAPES'):       # "N,K;N,K": other shapes (e.g. 5120,40960: 640 k-tiles per output tile, the k-loop alone)
+    SHAPES = tuple((int(a.split(',')[0]), int(a.split(',')[1]), a) for a in os.environ['MG_LIB_GEMM_SHAPES'].split(';'))
+for (N, K, name) in SHAPES:
     A = torch.randn(M, K, device=dev, generator=g).bfloat16()
     Wt = (torch.randn(N, K, device=dev, generator=g) * 0.02).bfloat16()
     bias_f = torch.randn(N, device=dev, generator=g)

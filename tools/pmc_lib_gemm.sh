@@ -3,8 +3,11 @@
 # separate rocprofv3 --pmc passes (never combined with other traces): clocks, matrix-pipe occupancy, L2 hit rate, fabric traffic
 R=$PWD; OUT=$R/gpurun_out/${1:-r04k}_pmc_lib_gemm.txt; : > $OUT
 cd /tmp; export TMPDIR=/tmp
+rm -rf /tmp/plg[0-9]*
 i=0
-for P in "FETCH_SIZE GRBM_GUI_ACTIVE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_WAIT_INST_ANY" "TCC_HIT_sum TCC_MISS_sum" "WRITE_SIZE"; do
+# PMC_SETS="a;b;c" overrides the counter passes (one rocprofv3 run per set)
+IFS=';' read -ra SETS <<< "${PMC_SETS:-FETCH_SIZE GRBM_GUI_ACTIVE;SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_WAIT_INST_ANY;TCC_HIT_sum TCC_MISS_sum;WRITE_SIZE}"
+for P in "${SETS[@]}"; do
   i=$((i+1)); rm -rf /tmp/plg$i
   MG_GEMM_VARIANT=${MG_GEMM_VARIANT:-0} rocprofv3 --pmc $P --kernel-trace --output-format csv -d /tmp/plg$i -o p -- python $R/tools/bench_lib_gemm.py 131040 > /tmp/plg$i.log 2>&1
 done
