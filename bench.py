@@ -307,7 +307,7 @@ def main():
 
     if args.gemm_variant:
         from wan.backend import lib as _lib
-        _lib.load().mg_gemm_set_variant(args.gemm_variant)
+        _lib.ab_library().__enter__().mg_gemm_set_variant(args.gemm_variant)      # measurement only: the whole process runs on the A/B library
     model = wan.modules.WanModel(**cfg, device=dev)
     model.init_weights(seed=0)
     model.eval().requires_grad_(False)

@@ -76,7 +76,7 @@ int mg_rmsnorm_rope_bf16(const uint16_t* x, int64_t ldx, uint16_t* out, int64_t 
  *     vp[head][tile][kc = (key%64)/8 (8)][d (128)][8 keys]
  * each tile = one contiguous 16 KiB block = the LDS image (pure LDS-DMA staging, conflict-free
  * ds_read_b128 with immediate offsets); keys >= L are zero.  The K row order is the one the 16x16x32 attention kernel
- * wants (its scores come out as the B operand of P.V without a shuffle); under mg_attn_set_variant(3) the rows are
+ * wants (its scores come out as the B operand of P.V without a shuffle); under the A/B library's mg_attn_set_variant(3) the rows are
  * in natural order (row = key % 64) for the A/B partner kernel.  kp/vp: heads*nt*8192 elements each,
  * 16-byte aligned.  No reference counterpart (flash_attn stages K/V inside its kernel). */
 int mg_pack_kv_bf16(const uint16_t* k, int64_t ldk, const uint16_t* v, int64_t ldv, int64_t L,
@@ -357,41 +357,38 @@ int mg_image_to_u8(const float* image, int H, int W, float lo, float hi, uint8_t
  * x [T][H][W][2C] -> out [2T][H][W][C], frame 2t from channels [0,C), 2t+1 from [C,2C). */
 int mg_vae_time_interleave_f32(const float* x, int T, int64_t HW, int C, float* out, void* stream);
 
+#ifdef MG_AB_BUILD
 /* ------------------------------------------------------------------------------------------
- * Debug / profiling hooks.  NOT part of the drop-in contract (no reference counterpart): used by
- * csrc/tools/selftest.cpp and tools/ to take s_memtime breakdowns of the hot loops and to force kernel
- * schedules for A/B measurements.  All are process-global switches; passing NULL / 0 restores the default.
+ * A/B LIBRARY ONLY (libmoviigen_hip_ab.so, built from the same sources with -DMG_AB_BUILD; the product library
+ * libmoviigen_hip.so exports NOTHING of this section).  Measurement partners and s_memtime hooks: used by
+ * csrc/tools/selftest.cpp, tools/ and the variant-agreement tests to force a kernel schedule and to take cycle breakdowns
+ * of the hot loops.  All are process-global switches, not thread-safe, not part of the drop-in contract; passing 0 / NULL
+ * restores the default.  The product path never loads this library (wan/backend/lib.py: load vs load_ab).
  * ---------------------------------------------------------------------------------------- */
-/* Tile schedule of mg_gemm_bf16 (same results bit for bit) — a process-global MEASUREMENT / TEST switch, not part of
- * the drop-in contract and not thread-safe; the default (0) selects by shape (11 for M > 256 and N > 128, else 2 / 1):
- * 11 = 256x256x64 tile, v_mfma_f32_16x16x32_bf16, persistent loop, 4 waves = ONE per SIMD (128x128 each); the k-tile is a
- *     GENERATED instruction schedule (tools/gen_gemm_v11_schedule.py): buffer_load ... lds with one 32-bit offset per piece,
- *     at most one other instruction behind each MFMA, counted lgkmcnt waits, the last 32 MFMAs of a k-tile behind the next
- *     k-tile's barrier; two schedules by K; bf16 outputs stored 16 bytes per lane (W rows permuted in LDS), fp32 outputs
- *     transposed through LDS and written / read-modified as whole row segments (110 + flags selects it with its experiment
- *     flags: 1 de-phased waves, 2 raster 0, 4 no stores, 8 skewed start, 16 direct fp32 epilogue);
- * 8 = (the round-3 default, A/B partner) 256x256x64 tile, v_mfma_f32_16x16x32_bf16, persistent loop (one workgroup per CU; the first k-tile of the next
- *     tile is fetched during the last k-tile of the current one), EIGHT waves in two ping-pong groups: in every interval
- *     between two barriers one group issues 16 MFMAs per wave while its SIMD partners read fragments and issue LDS-DMA;
- * 7 = the same tile and loop with 4 waves = ONE per SIMD (128x128 each), LDS-DMA pieces and fragment reads spread
- *     between the wave's own MFMAs (A/B partner);
- * 2 = 256x128x64 tile, 8 waves, 3-stage LDS ring with counted vmcnt (M > 128, else 1);
- * 1 = 128x128x64 tile, 4 waves, 2 stages. */
-void mg_gemm_set_variant(int variant);
+/* Tile schedule of mg_gemm_bf16 for M > 256 and N > 128 (same results bit for bit); 0 = the product's rule (12, else 2 / 1).
+ * Returns MG_ERR_ARG for a number that names no variant (no silent aliases).
+ * 12 = (product) 256x256x64 tile, v_mfma_f32_16x16x32_bf16, persistent, 4 waves = ONE per SIMD; a stage is refilled WHILE it is
+ *     consumed — loads two k-tiles ahead, three barriers per k-tile, none behind a drained memory pipe; the k-tile body is a GENERATED
+ *     schedule (tools/gen_gemm_v12_schedule.py) in a single self-looping block (200 + flags: 2 raster 0, 4 no stores, 16 direct fp32
+ *     epilogue, 32 * (1 + s) generated body s);
+ * 11 = the round-4 default: the same tile and epilogues, ONE barrier per k-tile behind vmcnt(0), the last 32 MFMAs of a k-tile behind
+ *     the next barrier (tools/gen_gemm_v11_schedule.py; 110 + flags: 1 de-phased waves, 2 raster 0, 4 no stores, 8 skewed start,
+ *     16 direct fp32 epilogue, 32 the every-4th-gap schedule);
+ * 8 = the round-3 default: EIGHT waves in two ping-pong groups, direct epilogues (the reference the epilogue tests compare with);
+ * 7 = one wave per SIMD, compiler-scheduled;   2 = 256x128x64, 8 waves, 3 stages;   1 = 128x128x64, 4 waves, 2 stages. */
+int mg_gemm_set_variant(int variant);
 
-/* Kernel behind mg_attn_fwd_bf16_hd128* and the matching K row order of mg_pack_kv_bf16 — a process-global
- * MEASUREMENT / TEST switch (same math in both), not part of the drop-in contract and not thread-safe:
- * 0 = "m16" (default): 4 waves x 64 queries, one wave per SIMD, v_mfma_f32_16x16x32_bf16, first-tile softmax reference in the MFMA's C operand,
- *     software-pipelined in 32-key units (csrc/attn_hd128_m16.hip);
- * 3 = "w64": the round-2 kernel (32x32x16 MFMA, per-row softmax reference; csrc/attn_hd128_w64.hip).
- * Other values select 0.  Pack and attend under the same setting. */
-void mg_attn_set_variant(int variant);
+/* Kernel behind mg_attn_fwd_bf16_hd128* and the matching K row order of mg_pack_kv_bf16 (pack and attend under the same setting):
+ * 0 = "m16" (the product's kernel); 3 = "w64", the round-2 kernel (32x32x16 MFMA, per-row softmax reference; NOT the same bits).
+ * Returns MG_ERR_ARG for anything else. */
+int mg_attn_set_variant(int variant);
 
 void mg_attn_w64_profile(unsigned long long* dev_buf);     /* both attention kernels: 4 waves x {fence, step A, step B, iterations} */
 void mg_attn_w64_debug(int flags);                         /* bit 0: keep the pipelined result of flagged blocks (no exact pass) */
 void mg_attn_w64_flag_counter(unsigned* dev_counter);      /* dev_counter[2]: [0] += query blocks whose pipelined pass flagged (m16: repeated with swept row maxima; w64: redone by the exact loop), [1] += m16 blocks that went on to the exact loop */
 void mg_gemm_debug_profile(unsigned long long* dev_buf);   /* GEMM variants 1/2: 8 waves x {wait+barrier, stage issue, MFMA, k-tiles} */
-void mg_gemm5_debug_profile(unsigned long long* dev_buf);   /* GEMM variant 7: 4 waves x {wait+barrier, k-step 0, k-step 1, k-tiles}; 8: 8 waves x {load, wait, MFMA, wait, phases} (64 words) */
+void mg_gemm5_debug_profile(unsigned long long* dev_buf);  /* GEMM variants 7 / 8 / 11 / 12: per-wave s_memtime sums (csrc/tools/selftest.cpp gemmprof prints each layout) */
+#endif /* MG_AB_BUILD */
 
 #ifdef __cplusplus
 }

@@ -68,14 +68,26 @@ __global__ __launch_bounds__(256) void pack_kv_kernel(const uint16_t* __restrict
     }
 }
 
+#ifdef MG_AB_BUILD
 int mg_attn_w64_launch(const uint16_t* q, int64_t ldq, const uint16_t* kp, const uint16_t* vp, uint16_t* o, int64_t ldo,
                        int64_t Lq, int64_t Lk, int heads, float c_log2, int nqb, float* lse, hipStream_t st);
+#endif
 int mg_attn_m16_launch(const uint16_t* q, int64_t ldq, const uint16_t* kp, const uint16_t* vp, uint16_t* o, int64_t ldo,
                        int64_t Lq, int64_t Lk, int heads, float c_log2, int prescaled, int nqb, float* lse, int reserve_cus,
                        hipStream_t st);
 
+// The product library has ONE head-dim-128 kernel (m16) and no switch.  The A/B library (-DMG_AB_BUILD) adds the round-2 kernel (w64, NOT the
+// same bits) behind mg_attn_set_variant — a process-global measurement switch that also selects the K row order mg_pack_kv_bf16 writes.
+#ifdef MG_AB_BUILD
 static int g_attn_variant = 0;      // 0 = m16 (default), 3 = w64 (round-2 kernel, A/B partner)
-extern "C" void mg_attn_set_variant(int v) { g_attn_variant = v == 3 ? 3 : 0; }
+extern "C" int mg_attn_set_variant(int v) {
+    if (v != 0 && v != 3) return MG_ERR_ARG;
+    g_attn_variant = v;
+    return MG_OK;
+}
+#else
+static constexpr int g_attn_variant = 0;
+#endif
 
 extern "C" int mg_pack_kv_bf16(const uint16_t* k, int64_t ldk, const uint16_t* v, int64_t ldv, int64_t L, int heads,
                                int head_dim, uint16_t* kp, uint16_t* vp, void* stream) {
@@ -99,8 +111,10 @@ static int attn_fwd_impl(const uint16_t* q, int64_t ldq, const uint16_t* kp, con
     const int nqb = (int)nqb64;
     const float c_log2 = scale * 1.4426950408889634f;
     hipStream_t st = (hipStream_t)stream;
+#ifdef MG_AB_BUILD
     if (g_attn_variant == 3)    // the round-2 kernel knows no pre-scaled q other than "its own factor is 1"
         return mg_attn_w64_launch(q, ldq, kp, vp, o, ldo, Lq, Lk, heads, prescaled ? 1.0f : c_log2, nqb, lse, st);
+#endif
     return mg_attn_m16_launch(q, ldq, kp, vp, o, ldo, Lq, Lk, heads, c_log2, prescaled, nqb, lse, reserve_cus, st);
 }
 

@@ -134,33 +134,41 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(
     mg_gemm_epilogue<EPI, 2, 2>(acc, m0 + wm * 64, n0 + wn * 64, l31, g, M, N, bias, gate, out, ldo);
 }
 
+int mg_gemm_v12_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_t ldw, const float* bias, int64_t M,
+                       int N, int K, int epilogue, void* out, int64_t ldo, const float* gate, hipStream_t st);       // gemm_bf16_v12.hip
+int mg_gemm_v2_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_t ldw, const float* bias, int64_t M,
+                      int N, int K, int epilogue, void* out, int64_t ldo, const float* gate, hipStream_t st);
+
+// Tile schedules in the PRODUCT library (libmoviigen_hip.so), chosen by shape alone — no switch, no process-global state:
+//   12 = 256x256x64 tile, 16x16x32 MFMA, one wave per SIMD, persistent, loads two k-tiles ahead (gemm_bf16_v12.hip): M > 256 and N > 128;
+//    2 = 256x128x64, 8 waves, 3 stages (gemm_bf16_v2.hip): everything narrower, and what variant 12's launcher hands back (one k-tile,
+//        bf16 pitches that only allow 8-byte stores, strides past its 32-bit tile offsets);   1 = 128x128x64, 2 stages (this file): M <= 128.
+// The A/B library (libmoviigen_hip_ab.so, built with -DMG_AB_BUILD: mg_selftest, the variant-agreement tests, tools/) adds the earlier
+// large-shape kernels — 11 (one barrier per k-tile, generated schedule), 8 (eight waves in two ping-pong groups), 7 (one wave per SIMD,
+// compiler-scheduled) — behind mg_gemm_set_variant, a process-global MEASUREMENT switch, and the s_memtime hooks.  Archived under
+// experiments/: 3, 4, 5, 6, 9, 10.
+#ifdef MG_AB_BUILD
 int mg_gemm_v7_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_t ldw, const float* bias, int64_t M,
                       int N, int K, int epilogue, void* out, int64_t ldo, const float* gate, hipStream_t st);
 int mg_gemm_v8_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_t ldw, const float* bias, int64_t M,
                       int N, int K, int epilogue, void* out, int64_t ldo, const float* gate, hipStream_t st);
-int mg_gemm_v12_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_t ldw, const float* bias, int64_t M,
-                       int N, int K, int epilogue, void* out, int64_t ldo, const float* gate, hipStream_t st);       // gemm_bf16_v12.hip
 int mg_gemm_v11_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_t ldw, const float* bias, int64_t M,
                        int N, int K, int epilogue, void* out, int64_t ldo, const float* gate, hipStream_t st);
-int mg_gemm_v2_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_t ldw, const float* bias, int64_t M,
-                      int N, int K, int epilogue, void* out, int64_t ldo, const float* gate, hipStream_t st);
-
-// tile schedule: 8 = 256x256, 8 waves in two ping-pong groups, persistent, 16x16x32 MFMA (gemm_bf16_v8.hip; the default for
-// M > 256 and N > 128); 7 = the same tile with 4 waves = one per SIMD (gemm_bf16_v7.hip, A/B partner); 2 = 256x128, 3 stages
-// (gemm_bf16_v2.hip; narrow shapes); 1 = 128x128 tile, 2 LDS stages (this file; M <= 128).  Archived under experiments/: 3 (8-wave
-// 256x256 on 32x32x16), 4 (16 waves), 5 (one 256x256 tile per workgroup), 6 (persistent, 32x32x16), 9 (8 with a ring refill).
-// Process-global and NOT thread-safe on purpose: a measurement / test switch (tools/, tests/conftest.py resets it after
-// every test), never touched by the product path — mg_gemm_bf16 itself picks by shape.
-unsigned long long* g_gemm5_prof = nullptr;   // debug hook of the 256x256 kernels (variants 5 and 7): 4 waves x {wait+barrier, first half, second half, k-tiles}
+unsigned long long* g_gemm5_prof = nullptr;   // s_memtime hook of the 256x256 kernels (7, 8, 11, 12)
 extern "C" void mg_gemm5_debug_profile(unsigned long long* dev_buf) { g_gemm5_prof = dev_buf; }
-static int g_gemm_variant = 0;   // 0 = by shape AND epilogue (below)
+static int g_gemm_variant = 0;   // 0 = the product's rule
 void mg_gemm_v11_set_flags(int f);
 void mg_gemm_v12_set_flags(int f);
-extern "C" void mg_gemm_set_variant(int v) {      // 110 + f / 200 + f: variant 11 / 12 with measurement flags f (gemm_bf16_v11.hip, gemm_bf16_v12.hip)
-    g_gemm_variant = v >= 200 ? 12 : v >= 110 ? 11 : v;
+extern "C" int mg_gemm_set_variant(int v) {      // 110 + f / 200 + f: variant 11 / 12 with measurement flags f (gemm_bf16_v11.hip, gemm_bf16_v12.hip)
+    const int base = v >= 200 ? 12 : v >= 110 ? 11 : v;
+    if (base != 0 && base != 1 && base != 2 && base != 7 && base != 8 && base != 11 && base != 12) return MG_ERR_ARG;      // no silent aliases
+    if ((v >= 110 && v - 110 >= 64 && v < 200) || v >= 200 + 256) return MG_ERR_ARG;
+    g_gemm_variant = base;
     mg_gemm_v11_set_flags(v >= 110 && v < 200 ? v - 110 : 0);
     mg_gemm_v12_set_flags(v >= 200 ? v - 200 : 0);
+    return MG_OK;
 }
+#endif
 
 extern "C" int mg_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_t ldw,
                             const float* bias, int64_t M, int N, int K, int epilogue, void* out,
@@ -172,21 +180,19 @@ extern "C" int mg_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* Wt, 
     if (bias && ((uintptr_t)bias & 15)) return MG_ERR_SHAPE;
     if (gate && ((uintptr_t)gate & 15)) return MG_ERR_SHAPE;
     if (M == 0) return MG_OK;
-    // default: variant 8, the persistent 256x256 loop on 16x16x32 MFMAs with eight waves in two ping-pong groups
-    // (profiles/r03j_gemm_v7_v8_v9.log: +1.5 ... +4 % over variant 7 = the same loop with one wave per SIMD, which was
-    // +2 ... +4 % over the 32x32x16 kernels of round 2, profiles/r03d_gemmshapes_*)
-    // default: variant 11 — variant 7's one-wave-per-SIMD structure with a GENERATED k-tile schedule (buffer loads straight to LDS,
-    // one instruction per MFMA gap, the last MFMAs of a k-tile behind the next barrier): +1.4 ... +3.1 % over variant 8 on the five
-    // shapes of a block at M = 131 040, identical bits (profiles/r04n_gemm_v11.log)
-    const int variant = g_gemm_variant ? g_gemm_variant : 11;
-    if (variant == 12 && M > 256 && N > 128)
-        return mg_gemm_v12_launch(A, lda, Wt, ldw, bias, M, N, K, epilogue, out, ldo, gate, (hipStream_t)stream);
+#ifdef MG_AB_BUILD
+    const int variant = g_gemm_variant ? g_gemm_variant : 12;
     if (variant == 11 && M > 256 && N > 128)
         return mg_gemm_v11_launch(A, lda, Wt, ldw, bias, M, N, K, epilogue, out, ldo, gate, (hipStream_t)stream);
-    if (variant >= 8 && M > 256 && N > 128)
+    if (variant == 8 && M > 256 && N > 128)
         return mg_gemm_v8_launch(A, lda, Wt, ldw, bias, M, N, K, epilogue, out, ldo, gate, (hipStream_t)stream);
     if (variant == 7 && M > 256 && N > 128)
         return mg_gemm_v7_launch(A, lda, Wt, ldw, bias, M, N, K, epilogue, out, ldo, gate, (hipStream_t)stream);
+#else
+    const int variant = 12;
+#endif
+    if (variant == 12 && M > 256 && N > 128)
+        return mg_gemm_v12_launch(A, lda, Wt, ldw, bias, M, N, K, epilogue, out, ldo, gate, (hipStream_t)stream);
     if (variant >= 2 && M > 128)  // tiny M: the 128-row tile wastes less (the 256x256 variants fall through to here for narrow shapes)
         return mg_gemm_v2_launch(A, lda, Wt, ldw, bias, M, N, K, epilogue, out, ldo, gate, (hipStream_t)stream);
     const int64_t tiles_m64 = (M + BM - 1) / BM;

@@ -235,10 +235,10 @@ int mg_gemm_v11_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64
     if (n_cu < 0) return MG_ERR_LAUNCH;
     n_cu &= ~7;                                         // one workgroup per CU (128 KiB LDS), a multiple of the 8 XCDs
     if (n_cu < 8) n_cu = 8;
-    // 32-bit byte offsets inside a tile: 255 rows x ld x 2 bytes + 128
-    if (lda * 2 * 256 > 0x7fffffffLL || ldw * 2 * 256 > 0x7fffffffLL || ldo * 4 * 128 > 0x7fffffffLL) return MG_ERR_SHAPE;
-    // the bf16 epilogues store 8 features = 16 bytes per lane
-    if ((epilogue == MG_EPI_BIAS_BF16 || epilogue == MG_EPI_BIAS_GELU_BF16) && (ldo & 7))
+    // 32-bit byte offsets inside a tile (255 rows x ld x 2 bytes + 128; the fp32 epilogue's 128 rows x ldo x 4) and bf16 pitches that only
+    // allow 8-byte stores: variant 8 takes those shapes, as it did when it was the default
+    const bool bf16_out = epilogue == MG_EPI_BIAS_BF16 || epilogue == MG_EPI_BIAS_GELU_BF16;
+    if (lda * 2 * 256 > 0x7fffffffLL || ldw * 2 * 256 > 0x7fffffffLL || ldo * (bf16_out ? 2 : 4) * 128 > 0x7fffffffLL || (bf16_out && (ldo & 7)))
         return mg_gemm_v8_launch(A, lda, Wt, ldw, bias, M, N, K, epilogue, out, ldo, gate, st);
     const int64_t tiles_m64 = (M + V11_BM - 1) / V11_BM;
     const int tiles_n = (N + V11_BN - 1) / V11_BN;

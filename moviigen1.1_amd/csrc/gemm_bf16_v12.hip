@@ -17,10 +17,12 @@
 // k-tile loads the next tile's k-tile 0; the LAST k-tile of a tile is a body without loads, reads-ahead and barriers (gemm_bf16_v12_last.inc):
 // its stage is the fp32 epilogues' transposition buffer, and the registers of the fragments read ahead are the epilogue's.  Behind the
 // epilogue a short tile prologue issues the next tile's k-tile 1 and reads its k-step-0 fragments of k-tile 0 (landed: vmcnt(0) + barrier
-// closed the last body).  Needs K >= 128 (two k-tiles); the launcher sends anything else to variant 11.
+// closed the last body).  Needs K >= 128 (two k-tiles); the launcher sends anything else to the general 256 x 128 kernel (gemm_bf16_v2.hip).
 #include "gemm_v11_common.h"
 
-extern unsigned long long* g_gemm5_prof;    // gemm_bf16.hip: mg_gemm5_debug_profile
+#ifdef MG_AB_BUILD
+extern unsigned long long* g_gemm5_prof;    // gemm_bf16.hip: mg_gemm5_debug_profile (A/B library only)
+#endif
 
 // SCHED = which generated body (tools/gen_gemm_v12_schedule.py: SCHEDULES); chosen in the launcher
 template <int EPI, int SCHED, bool PROF = false>
@@ -275,18 +277,23 @@ __global__ __launch_bounds__(V11_THREADS, 1) void gemm_bf16_v12_kernel(
     }
 }
 
-int mg_gemm_v11_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_t ldw, const float* bias, int64_t M, int N, int K,
-                       int epilogue, void* out, int64_t ldo, const float* gate, hipStream_t st);      // gemm_bf16_v11.hip
+int mg_gemm_v2_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_t ldw, const float* bias, int64_t M, int N, int K,
+                      int epilogue, void* out, int64_t ldo, const float* gate, hipStream_t st);      // gemm_bf16_v2.hip
 
+#ifdef MG_AB_BUILD
 static int g_v12_flags = 0;     // measurement bits (mg_gemm_set_variant(200 + flags)): 2 = raster 0 always, 4 = no stores (timing only), 16 = fp32 outputs: direct epilogue, 32 * (1 + s) = generated body s (0 / 2)
 void mg_gemm_v12_set_flags(int f) { g_v12_flags = f; }
+#else
+static constexpr int g_v12_flags = 0;
+#endif
 
 int mg_gemm_v12_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_t ldw, const float* bias, int64_t M,
                        int N, int K, int epilogue, void* out, int64_t ldo, const float* gate, hipStream_t st) {
-    // one k-tile only, unaligned bf16 pitches, strides past the 32-bit tile offsets: variant 11's launcher decides (and falls back itself)
-    if (K < 2 * V11_BK || lda * 2 * 256 > 0x7fffffffLL || ldw * 2 * 256 > 0x7fffffffLL || ldo * 4 * 128 > 0x7fffffffLL ||
+    // one k-tile only, bf16 pitches that only allow 8-byte stores, strides past the 32-bit tile offsets: the general 256 x 128 kernel
+    if (K < 2 * V11_BK || lda * 2 * 256 > 0x7fffffffLL || ldw * 2 * 256 > 0x7fffffffLL ||
+        ldo * ((epilogue == MG_EPI_BIAS_BF16 || epilogue == MG_EPI_BIAS_GELU_BF16) ? 2 : 4) * 128 > 0x7fffffffLL ||
         ((epilogue == MG_EPI_BIAS_BF16 || epilogue == MG_EPI_BIAS_GELU_BF16) && (ldo & 7)))
-        return mg_gemm_v11_launch(A, lda, Wt, ldw, bias, M, N, K, epilogue, out, ldo, gate, st);
+        return mg_gemm_v2_launch(A, lda, Wt, ldw, bias, M, N, K, epilogue, out, ldo, gate, st);
     int n_cu = mg_cu_count();
     if (n_cu < 0) return MG_ERR_LAUNCH;
     n_cu &= ~7;
@@ -303,14 +310,24 @@ int mg_gemm_v12_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64
     // which generated body: measurement override in bits 5-7 of the flags (mg_gemm_set_variant(200 + 32 * (1 + s))), else body 0 (the six
     // bodies tried differ by < 1 %, profiles/r05c / r05g / r05h_gemm_v12_sched.log)
     const int sched = (g_v12_flags >> 5) == 3 ? 2 : 0;
+#ifdef MG_AB_BUILD
+#define V12_PROF_BUF(P) ((P) ? g_gemm5_prof : nullptr)
+#else
+#define V12_PROF_BUF(P) nullptr
+#endif
 #define LAUNCH_S(E, S, P)                                                                                                                \
     hipLaunchKernelGGL((gemm_bf16_v12_kernel<E, S, P>), grid, block, 0, st, A, lda, Wt, ldw, bias, M, N, K, out, ldo, gate, tiles_m, tiles_n, \
-                       raster, g_v12_flags & 31, P ? g_gemm5_prof : nullptr)
+                       raster, g_v12_flags & 31, V12_PROF_BUF(P))
+#ifdef MG_AB_BUILD
 #define LAUNCH(E) do { if (sched == 2) LAUNCH_S(E, 2, false); else LAUNCH_S(E, 0, false); } while (0)
     if (g_gemm5_prof && epilogue == MG_EPI_BIAS_BF16) {
         LAUNCH_S(MG_EPI_BIAS_BF16, 0, true);
         return mg_check_launch();
     }
+#else
+    (void)sched;
+#define LAUNCH(E) LAUNCH_S(E, 0, false)
+#endif
     switch (epilogue) {
         case MG_EPI_BIAS_BF16: LAUNCH(MG_EPI_BIAS_BF16); break;
         case MG_EPI_BIAS_GELU_BF16: LAUNCH(MG_EPI_BIAS_GELU_BF16); break;
@@ -319,5 +336,6 @@ int mg_gemm_v12_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64
     }
 #undef LAUNCH
 #undef LAUNCH_S
+#undef V12_PROF_BUF
     return mg_check_launch();
 }

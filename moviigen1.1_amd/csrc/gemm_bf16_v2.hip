@@ -27,8 +27,10 @@ typedef __attribute__((address_space(3))) void* v2_lptr_t;
 MG_DEV void v2_glds16(const void* g, void* l) { __builtin_amdgcn_global_load_lds((v2_gptr_t)g, (v2_lptr_t)l, 16, 0, 0); }
 
 static unsigned long long* g_gemm_prof = nullptr;
-// debug hook (not in the public header): 8 waves x 4 s_memtime sums {wait+barrier, stage issue, MFMA segment, k-tiles}
+#ifdef MG_AB_BUILD
+// s_memtime hook (A/B library only): 8 waves x 4 sums {wait+barrier, stage issue, MFMA segment, k-tiles}
 extern "C" void mg_gemm_debug_profile(unsigned long long* dev_buf) { g_gemm_prof = dev_buf; }
+#endif
 
 template <int EPI, bool PROF = false>
 __global__ __launch_bounds__(V2_THREADS, 2) void gemm_bf16_v2_kernel(

@@ -1,12 +1,19 @@
 """ctypes binding of libmoviigen_hip.so (C-ABI declared in include/moviigen_hip.h).
 
 The product path has NO fallback: if the shared library is missing or a kernel returns an error
-code this module raises — it never routes to torch ops or to the oracle."""
+code this module raises — it never routes to torch ops or to the oracle.
+
+Two builds of the same sources exist (csrc/Makefile): the PRODUCT library libmoviigen_hip.so — one kernel per shape
+class, no kernel-selection switch, no profiling hook — is what `load()` returns and what every `wan` module runs on.
+libmoviigen_hip_ab.so (-DMG_AB_BUILD) adds the measurement partners (GEMM variants 7 / 8 / 11, the w64 attention kernel),
+`mg_gemm_set_variant` / `mg_attn_set_variant` and the s_memtime hooks; only tests/, tools/ and bench.py's measurement
+flags ask for it, through `load_ab()` or the `ab_library()` scope."""
 import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.normpath(os.path.join(_HERE, '..', '..', 'lib', 'libmoviigen_hip.so'))
+LIB_AB_PATH = os.path.normpath(os.path.join(_HERE, '..', '..', 'lib', 'libmoviigen_hip_ab.so'))
 
 c_i64, c_int, c_f32, c_vp = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 
@@ -25,8 +32,6 @@ SIGNATURES = {
     'mg_attn_merge_f32': [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_vp],
     'mg_attn_fwd_bf16_generic': [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_int, c_int,
                                  c_f32, c_vp],
-    'mg_attn_set_variant': [c_int],
-    'mg_gemm_set_variant': [c_int],
     'mg_sinusoid_embed': [c_vp, c_int, c_int, c_int, c_vp, c_vp],
     'mg_gemv_f32': [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp],
     'mg_add_rows_f32': [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp],
@@ -57,50 +62,94 @@ SIGNATURES = {
     'mg_sp_all_gather': [c_vp, c_vp, c_vp, c_i64, c_vp],
     'mg_shard_all_gather': [c_vp, c_vp, c_vp, c_i64, c_vp],
     'mg_gate_residual_f32': [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int, c_vp],
-    # debug / profiling hooks (declared in the header's last section; never called by the product path)
-    'mg_attn_w64_profile': [c_vp],
-    'mg_attn_w64_debug': [c_int],
-    'mg_attn_w64_flag_counter': [c_vp],
-    'mg_gemm_debug_profile': [c_vp],
-    'mg_gemm5_debug_profile': [c_vp],
     'mg_image_to_u8': [c_vp, c_int, c_int, c_f32, c_f32, c_vp, c_vp],
     'mg_sp_pack_qkv_bf16': [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_int, c_vp, c_vp],
     'mg_sp_copy_blocks_bf16': [c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_int, c_i64, c_int, c_vp],
     'mg_sp_unpack_o_bf16': [c_vp, c_i64, c_int, c_int, c_int, c_int, c_vp, c_i64, c_vp],
 }
-_RESTYPE = {'mg_version': ctypes.c_char_p, 'mg_vae_attn_workspace_floats': ctypes.c_int64, 'mg_attn_set_variant': None,
-            'mg_gemm_set_variant': None, 'mg_attn_w64_profile': None,
+# the header's MG_AB_BUILD section: exported by libmoviigen_hip_ab.so only
+SIGNATURES_AB = {
+    'mg_attn_set_variant': [c_int],
+    'mg_gemm_set_variant': [c_int],
+    'mg_attn_w64_profile': [c_vp],
+    'mg_attn_w64_debug': [c_int],
+    'mg_attn_w64_flag_counter': [c_vp],
+    'mg_gemm_debug_profile': [c_vp],
+    'mg_gemm5_debug_profile': [c_vp],
+}
+_RESTYPE = {'mg_version': ctypes.c_char_p, 'mg_vae_attn_workspace_floats': ctypes.c_int64, 'mg_attn_w64_profile': None,
             'mg_attn_w64_debug': None, 'mg_attn_w64_flag_counter': None, 'mg_gemm_debug_profile': None, 'mg_gemm5_debug_profile': None}
-DEFAULT_GEMM_VARIANT = 0   # must match g_gemm_variant in csrc/gemm_bf16.hip (0 = by shape and epilogue)
+DEFAULT_GEMM_VARIANT = 0   # mg_gemm_set_variant(0) = the product's rule by shape (A/B library)
 
 ERRORS = {-1: 'MG_ERR_ARG (null pointer / bad enum)', -2: 'MG_ERR_SHAPE (unsupported shape or alignment)',
           -3: 'MG_ERR_LAUNCH (kernel launch failed)', -4: 'MG_ERR_UNAVAILABLE (librccl could not be bound)',
           -5: 'MG_ERR_COMM (an RCCL call failed)'}
 
 _lib = None
-DEFAULT_ATTN_VARIANT = 0   # must match g_attn_variant in csrc/attn_hd128.hip
+_lib_ab = None
+_use_ab = False
+DEFAULT_ATTN_VARIANT = 0   # mg_attn_set_variant(0) = the product's kernel (A/B library)
 
 
 class MoviigenHipError(RuntimeError):
     pass
 
 
-def load():
-    """dlopen the in-tree library; raises (never falls back) when it is absent."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def _open(path, sigs):
+    if not os.path.exists(path):
         raise MoviigenHipError(
-            f'{LIB_PATH} not found: build it with `python __graft_entry__.py build` '
+            f'{path} not found: build it with `python __graft_entry__.py build` '
             '(hipcc --offload-arch=gfx950); there is no CPU/torch fallback for the hot path')
-    lib = ctypes.CDLL(LIB_PATH)
-    for name, args in SIGNATURES.items():
+    lib = ctypes.CDLL(path)
+    for name, args in sigs.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.argtypes = args
         fn.restype = _RESTYPE.get(name, ctypes.c_int)
-    _lib = lib
     return lib
+
+
+def load():
+    """dlopen the in-tree PRODUCT library; raises (never falls back) when it is absent.  Inside an `ab_library()` scope — tests and
+    measurement tools only — the A/B library instead."""
+    global _lib
+    if _use_ab:
+        return load_ab()
+    if _lib is None:
+        _lib = _open(LIB_PATH, SIGNATURES)
+    return _lib
+
+
+def load_ab():
+    """the A/B library (measurement partners, kernel-selection switches, s_memtime hooks): tests/, tools/, bench.py --gemm-variant"""
+    global _lib_ab
+    if _lib_ab is None:
+        _lib_ab = _open(LIB_AB_PATH, {**SIGNATURES, **SIGNATURES_AB})
+    return _lib_ab
+
+
+class ab_library:
+    """`with lib.ab_library():` — every kernel call of the scope goes to the A/B library (so that `mg_*_set_variant` and the hooks act on
+    what `wan.backend.ops` runs); the switches are reset when the scope ends.  NOT for product code: process-global, not thread-safe."""
+
+    def __enter__(self):
+        global _use_ab
+        self._prev, _use_ab = _use_ab, True
+        return load_ab()
+
+    def __exit__(self, *exc):
+        global _use_ab
+        if self._prev:          # an inner scope: the outermost one resets
+            return False
+        h = load_ab()
+        h.mg_attn_set_variant(DEFAULT_ATTN_VARIANT)
+        h.mg_gemm_set_variant(DEFAULT_GEMM_VARIANT)
+        h.mg_attn_w64_debug(0)
+        h.mg_attn_w64_profile(None)
+        h.mg_attn_w64_flag_counter(None)
+        h.mg_gemm_debug_profile(None)
+        h.mg_gemm5_debug_profile(None)
+        _use_ab = self._prev
+        return False
 
 
 def call(name, *args):

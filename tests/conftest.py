@@ -43,7 +43,8 @@ def _reset_kernel_selection(request):
     if 'gpu' not in request.keywords:
         return
     from wan.backend import lib
-    h = lib._lib
+    assert not lib._use_ab, 'a test left an ab_library() scope open'
+    h = lib._lib_ab      # the product library has no switches; the A/B one is reset if a test loaded it
     if h is not None:
         h.mg_attn_set_variant(lib.DEFAULT_ATTN_VARIANT)
         h.mg_gemm_set_variant(lib.DEFAULT_GEMM_VARIANT)

@@ -133,30 +133,34 @@ def test_gemm_tile_variants_agree(dev, M, N, K):
     """the tile schedules (128x128, 256x128, 256x256 with one wave per SIMD: one tile per workgroup, and the persistent
     tile loop — the last three shapes have more tiles than CUs, so its workgroups iterate: two with < 32 tile columns = the
     chip-wide 8x32 super-tile raster of variant 8, incl. a partial band, one with 33 = the per-XCD band raster, one narrow with
-    K > 8192 = the 16x16 super-tile raster — and the default, variant 11: variant 7's structure with a generated k-tile schedule,
-    buffer loads straight to LDS and the rotated tail; K = 64 is its one-k-tile case, K = 8256 its second schedule) give the same
-    bits, ragged edges included."""
+    K > 8192 = the 16x16 super-tile raster —, variant 11 (one barrier per k-tile, generated schedule, rotated tail; K = 64 is its
+    one-k-tile case, K = 8256 its second schedule) and the product's variant 12 (a stage refilled while it is consumed; K = 64 goes to
+    the 256x128 kernel, K = 128 is its two-k-tile edge) give the same bits, ragged edges included — in the A/B library and in the
+    PRODUCT library, which has no switch."""
     from wan.backend import lib, ops
     a = W.randn((M, K), 16).bfloat16().to(dev)
     w = (W.randn((N, K), 17) * 0.05).bfloat16().to(dev)
     b = W.randn((N,), 18).to(dev)
     outs = []
-    try:
-        for v in (0, 1, 2, 7, 8, 11):
-            lib.load().mg_gemm_set_variant(v)
-            o = torch.full((M + 1, N), -7.0, dtype=torch.float32, device=dev)      # guard row: no write past M
-            ops.gemm(a, w, b, ops.BIAS_F32, o[:M])
-            assert (o[M] == -7.0).all()
-            outs.append(o[:M].clone())
-    finally:
-        lib.load().mg_gemm_set_variant(lib.DEFAULT_GEMM_VARIANT)
+
+    def run():
+        o = torch.full((M + 1, N), -7.0, dtype=torch.float32, device=dev)      # guard row: no write past M
+        ops.gemm(a, w, b, ops.BIAS_F32, o[:M])
+        assert (o[M] == -7.0).all()
+        outs.append(o[:M].clone())
+    run()                                   # the PRODUCT library (its own rule by shape: 12, else 2 / 1)
+    with lib.ab_library() as h:             # the measurement partners live in the A/B library
+        for v in (0, 1, 2, 7, 8, 11, 12):
+            assert h.mg_gemm_set_variant(v) == 0
+            run()
+        assert h.mg_gemm_set_variant(9) != 0 and h.mg_gemm_set_variant(13) != 0       # unknown numbers are refused, not aliased
     assert all(torch.equal(outs[0], o) for o in outs[1:])
 
 
 @pytest.mark.parametrize('M,N,K', [(1030, 1284, 640), (4200, 4100, 128), (9000, 2304, 64), (2100, 8448, 8256)])
 @pytest.mark.parametrize('epi', [0, 1, 2, 3])
 def test_gemm_default_epilogues_match_direct_ones(dev, M, N, K, epi):
-    """variant 11 (the default for M > 256, N > 128) has its own epilogues — bf16 outputs: W rows staged in a permuted order so that
+    """variants 11 and 12 (the product's kernel for M > 256, N > 128) share their own epilogues — bf16 outputs: W rows staged in a permuted order so that
     a lane stores 8 consecutive features (16 bytes); fp32 outputs: the wave's block transposed through LDS and written as whole row
     segments, with the residual read the same way — against variant 8's direct epilogue: EVERY element, bit for bit, full and ragged
     blocks, one k-tile and both k-loop schedules, outputs with a row pitch > N, and a bf16 pitch that only allows 8-byte stores (the
@@ -169,17 +173,20 @@ def test_gemm_default_epilogues_match_direct_ones(dev, M, N, K, epi):
     for pitch in (N, N + 24, N + 4):
         r0 = W.randn((M + 1, pitch), 30).to(dev)
         outs = []
-        try:
-            for v in (8, 11):
-                lib.load().mg_gemm_set_variant(v)
-                o = r0.clone() if f32 else r0.bfloat16()
-                ops.gemm(a, w, b, epi, o[:M, :N], gate=g if epi == 2 else None)
-                outs.append(o)
-        finally:
-            lib.load().mg_gemm_set_variant(lib.DEFAULT_GEMM_VARIANT)
-        assert torch.equal(outs[0], outs[1]), (pitch, (outs[0].float() - outs[1].float()).abs().max().item())
+
+        def run():
+            o = r0.clone() if f32 else r0.bfloat16()
+            ops.gemm(a, w, b, epi, o[:M, :N], gate=g if epi == 2 else None)
+            outs.append(o)
+        with lib.ab_library() as h:
+            for v in (8, 11, 12):
+                h.mg_gemm_set_variant(v)
+                run()
+        run()                               # the product library
         ref = r0 if f32 else r0.bfloat16()
-        assert torch.equal(outs[1][M], ref[M]) and torch.equal(outs[1][:, N:], ref[:, N:])      # nothing outside [M, N]
+        for o in outs[1:]:
+            assert torch.equal(outs[0], o), (pitch, (outs[0].float() - o.float()).abs().max().item())
+            assert torch.equal(o[M], ref[M]) and torch.equal(o[:, N:], ref[:, N:])      # nothing outside [M, N]
 
 
 def test_gemm_rejects_bad_shapes(dev):
@@ -231,13 +238,13 @@ def test_attention_rescale_branch(dev, attn_variant, spikes):
     k[0, 500] = (q[0, 100] * spikes[1]).clone()        # tile 7 spikes for query 100
     ref = dit.attention(q[0].float(), k[0].float(), v[0].float(), Lk, True)
     cnt = torch.zeros(2, dtype=torch.int32, device=dev)
-    h = lib.load()
-    h.mg_attn_w64_flag_counter(cnt.data_ptr())
-    try:
+    out_product = flash_attention(q.to(dev), k.to(dev), v.to(dev))[0].float() if attn_variant == 0 else None
+    with lib.ab_library() as h:             # the flag counter is a hook of the A/B build (the same kernel source)
+        h.mg_attn_w64_flag_counter(cnt.data_ptr())
         out = flash_attention(q.to(dev), k.to(dev), v.to(dev))[0].float()
         torch.cuda.synchronize()
-    finally:
-        h.mg_attn_w64_flag_counter(None)
+    if out_product is not None:
+        assert torch.equal(out, out_product)       # the product library's kernel is that kernel
     assert scale_err(out, ref) < 2e-2
     # the spiked rows themselves (they are one-hot: the output row is the spiked key's value row)
     assert (out[7, 0].cpu() - v[0, 300, 0].float()).abs().max().item() < 2e-2
@@ -316,11 +323,14 @@ def test_attention_reserved_cus_same_bits(dev):
 
 @pytest.fixture(params=[0, 3], ids=['m16', 'w64'])
 def attn_variant(request):
-    """run a test under every kernel selection of mg_attn_fwd_bf16_hd128."""
+    """run a test on the product library's head-dim-128 kernel (m16) and, inside an A/B-library scope, on its measurement partner (w64)."""
     from wan.backend import lib
-    lib.load().mg_attn_set_variant(request.param)
-    yield request.param
-    lib.load().mg_attn_set_variant(lib.DEFAULT_ATTN_VARIANT)
+    if request.param == 0:
+        yield 0
+        return
+    with lib.ab_library() as h:
+        assert h.mg_attn_set_variant(request.param) == 0
+        yield request.param
 
 
 def test_small_fp32_kernels(dev):
@@ -689,8 +699,10 @@ def test_fullsize_attention_properties(dev, variant):
     vpk = torch.empty(n_pk, dtype=torch.bfloat16, device=dev)
     o = torch.empty(L, N * 128, dtype=torch.bfloat16, device=dev)
     sc = 1 / math.sqrt(128)
-    lib.load().mg_attn_set_variant(variant)
-    try:
+    import contextlib
+    with (lib.ab_library() if variant else contextlib.nullcontext()):
+        if variant:
+            lib.load().mg_attn_set_variant(variant)
         # (1) rows of softmax sum to one: V = const  =>  O = const, for EVERY query and head
         ops.pack_kv(k, torch.full_like(v, 0.5), N, kpk, vpk)
         ops.attention_hd128(q, kpk, vpk, o, L, N, sc)
@@ -711,8 +723,6 @@ def test_fullsize_attention_properties(dev, variant):
         q6 = (q.float() * 6).bfloat16()
         ops.attention_hd128(q6, kpk, vpk, o, L, N, sc)
         _attn_rows_check(q6, kp, vp, o, rows, (0, 17, 39), sc)
-    finally:
-        lib.load().mg_attn_set_variant(lib.DEFAULT_ATTN_VARIANT)
 
 
 def test_fullsize_gemm_properties(dev):

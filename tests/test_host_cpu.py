@@ -17,22 +17,28 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_cabi_exports_every_declared_symbol():
-    """the library loads and exports exactly what include/moviigen_hip.h declares (no compute)."""
+    """both libraries load and export exactly what include/moviigen_hip.h declares for them (no compute): the PRODUCT library
+    everything outside the header's MG_AB_BUILD section — in particular no kernel-selection switch and no profiling hook —, the A/B
+    library all of it."""
+    import subprocess
     from wan.backend import lib
     hdr = open(os.path.join(ROOT, 'include', 'moviigen_hip.h')).read()
-    declared = set(re.findall(r'\b(mg_[a-z0-9_]+)\s*\(', hdr))
-    assert len(declared) >= 23
-    assert declared == set(lib.SIGNATURES), declared ^ set(lib.SIGNATURES)
-    handle = lib.load()
-    for name in declared:
-        assert hasattr(handle, name), name
-    assert handle.mg_abi_version() == 7
-    assert b'gfx950' in handle.mg_version()
-    # and nothing undeclared leaks out of the .so: every exported mg_* symbol is in the header
-    import subprocess
-    nm = subprocess.run(['nm', '-D', '--defined-only', lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
-    exported = set(re.findall(r'\bT (mg_[a-z0-9_]+)$', nm, re.M))
-    assert exported and exported <= declared, exported - declared
+    m = re.search(r'#ifdef MG_AB_BUILD(.*?)#endif /\* MG_AB_BUILD \*/', hdr, re.S)
+    assert m
+    decl = lambda txt: set(re.findall(r'^(?:int|void|const char\*|int64_t)\s+(mg_[a-z0-9_]+)\s*\(', txt, re.M))
+    ab_only = decl(m.group(1))
+    product = decl(hdr.replace(m.group(1), ''))
+    assert len(product) >= 40 and ab_only == set(lib.SIGNATURES_AB), ab_only ^ set(lib.SIGNATURES_AB)
+    assert product == set(lib.SIGNATURES), product ^ set(lib.SIGNATURES)
+    assert not any('set_variant' in n or 'debug' in n or 'profile' in n for n in product)
+    for path, want, handle in ((lib.LIB_PATH, product, lib.load()), (lib.LIB_AB_PATH, product | ab_only, lib.load_ab())):
+        for name in want:
+            assert hasattr(handle, name), (path, name)
+        assert handle.mg_abi_version() == 8
+        assert b'gfx950' in handle.mg_version()
+        nm = subprocess.run(['nm', '-D', '--defined-only', path], capture_output=True, text=True, check=True).stdout
+        exported = set(re.findall(r'\bT (mg_[a-z0-9_]+)$', nm, re.M))
+        assert exported == want, (path, exported ^ want)      # nothing undeclared leaks out, nothing declared is missing
 
 
 def test_product_never_imports_oracle():

@@ -26,6 +26,9 @@ KERNELS = [
     # variant 11: the k-tile is generated inline assembly (128 MFMAs, 32 LDS reads, 16 buffer loads to LDS + 16 M0 writes, 18
     # waits, 17 s_nop, one barrier = 116) plus the loop's own bookkeeping blocks; the limit checks that the compiler adds no more
     ('gemm_bf16_v11.hip', 'gemm_bf16_v11_kernel', r'kernelILi\dELi\dELb1E', 128, 165),
+    # variant 12: ONE self-looping block — 128 MFMAs + 32 LDS reads + 16 loads + 16 M0 writes + 6 state toggles + 5 counted waits + 3 x
+    # (wait + barrier) + ~17 s_nop 0 in front of the M0 writes + the loop's add / compare / branch = 101
+    ('gemm_bf16_v12.hip', 'gemm_bf16_v12_kernel', r'kernelILi\dELi\dELb1E', 128, 108),
     ('attn_hd128_m16.hip', 'attn_hd128_m16_kernel', r'kernelILb1E', 128, 330),
 ]
 FORBIDDEN = ('scratch_', 'v_cndmask', 'v_readfirstlane')
@@ -136,6 +139,102 @@ def store_hazards(src):
     return out
 
 
+def sgprs(op):
+    m = re.fullmatch(r's\[(\d+):(\d+)\]', op)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.fullmatch(r's(\d+)', op)
+    return {int(m.group(1))} if m else set()
+
+
+def lane_read_hazards(src):
+    """A VALU write of an SGPR (v_readfirstlane / v_readlane) followed within 5 wait states by a VMEM instruction that reads it — as a
+    buffer resource or a scalar offset.  hipcc keeps that distance for the VMEM instructions it emits itself; an INLINE-ASSEMBLY load
+    (the LDS-DMA loads of GEMM variants 11 / 12) is opaque to it, and a spill reload (v_readlane) placed directly in front of one would be
+    5 wait states short.  Scans every kernel of a source file."""
+    out = []
+    text = device_asm(src)
+    funcs = re.split(r'^(_Z\w+|\w+_kernel\w*):', text, flags=re.M)
+    for name, body in zip(funcs[1::2], funcs[2::2]):
+        lines = [ln.strip().split(';')[0].strip() for ln in body.split('.Lfunc_end')[0].splitlines()
+                 if ln.startswith('\t') and not ln.strip().startswith((';', '.'))]
+        for i, a in enumerate(lines):
+            if not a.startswith(('v_readfirstlane_b32', 'v_readlane_b32')):
+                continue
+            dst = sgprs(a.split()[1].rstrip(','))
+            states = 0
+            for b in lines[i + 1:i + 8]:
+                op = b.split()[0]
+                if op.startswith(('buffer_', 'global_load_lds', 's_buffer')):
+                    used = set()
+                    for o in b[len(op):].replace(' offen', '').replace(' lds', '').split(','):
+                        o = o.strip().split()[0] if o.strip() else ''
+                        used |= sgprs(o)
+                    if dst & used and states < 5:
+                        out.append(f'{name[:60]}: `{a}` {states} wait states in front of `{b}`')
+                    break
+                states += (int(b.split()[1]) + 1) if op == 's_nop' else 1
+                if states >= 5 or op.startswith(('s_cbranch', 's_branch', 's_endpgm')):
+                    break
+    return out
+
+
+def exit_pad(src, frag, skip, n_mfma):
+    """GEMM variant 12: the k-loop's MFMAs are inline assembly, so the compiler does not know their results are in flight when the loop
+    ends; the source pads with `s_nop 15` x 2 right behind the loop.  Checks that no accumulator instruction stands between the loop's
+    back edge and that pad, in every instantiation."""
+    out = []
+    text = device_asm(src)
+    funcs = re.split(r'^(_Z\w+):', text, flags=re.M)
+    for name, body in zip(funcs[1::2], funcs[2::2]):
+        if frag not in name or re.search(skip, name):
+            continue
+        lines = [ln.strip().split(';')[0].strip() for ln in body.split('.Lfunc_end')[0].splitlines() if ln.strip() and not ln.strip().startswith(';')]
+        found = False
+        for i, ln in enumerate(lines):
+            m = re.match(r'(\.LBB\d+_\d+):', ln)
+            if not m:
+                continue
+            j = i + 1
+            blk = []
+            while j < len(lines) and not re.match(r'\.LBB\d+_\d+:', lines[j]):
+                blk.append(lines[j])
+                j += 1
+            back = [k for k, x in enumerate(blk) if re.search(r's_cbranch\w*\s+' + re.escape(m.group(1)) + r'\b', x)]
+            if not back or sum(1 for x in blk[:back[-1]] if x.startswith('v_mfma_')) != n_mfma:
+                continue
+            found = True
+            # walk every control-flow path from the back edge's fall-through until it meets the pad
+            label_at = {mm.group(1): k for k, x in enumerate(lines) for mm in [re.match(r'(\.LBB\d+_\d+):', x)] if mm}
+            start = i + 1 + back[-1] + 1
+            todo, seen = [start], set()
+            while todo:
+                k = todo.pop()
+                while k < len(lines) and k not in seen:
+                    seen.add(k)
+                    x = lines[k]
+                    if k == i:                  # back in the loop (the second pass through the same body): MFMA behind MFMA, as on the back edge
+                        break
+                    if x.startswith('s_nop 15'):
+                        break
+                    if x.startswith(('v_accvgpr', 'v_mfma')):
+                        out.append(f'{name[:60]}: `{x}` between the k-loop and its exit pad')
+                        break
+                    mb = re.match(r's_(c?)branch\w*\s+(\.LBB\d+_\d+)', x)
+                    if mb:
+                        if mb.group(2) != m.group(1):
+                            todo.append(label_at[mb.group(2)])
+                        if not mb.group(1):
+                            break
+                    if x.startswith('s_endpgm'):
+                        out.append(f'{name[:60]}: a path from the k-loop reaches s_endpgm without the pad')
+                        break
+                    k += 1
+        if not found:
+            out.append(f'{name[:60]}: no self-looping block with {n_mfma} MFMAs')
+    return out
+
+
 def main():
     allp = []
     for k in KERNELS:
@@ -147,7 +246,11 @@ def main():
         if src.endswith('.hip'):
             n_src += 1
             allp += ['store data hazard: ' + h for h in store_hazards(src)]
-    print(f'store-data / packed-fp32 hazard scan: {n_src} source files')
+            allp += ['lane-read hazard: ' + h for h in lane_read_hazards(src)]
+    print(f'store-data / packed-fp32 and lane-read / VMEM hazard scans: {n_src} source files')
+    pads = exit_pad('gemm_bf16_v12.hip', 'gemm_bf16_v12_kernel', r'kernelILi\dELi\dELb1E', 128)
+    print(f'variant 12 exit pad: {"ok" if not pads else "VIOLATED"}')
+    allp += pads
     for p in allp:
         print('VIOLATION:', p)
     return 1 if allp else 0

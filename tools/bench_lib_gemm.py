@@ -17,7 +17,7 @@ from wan.backend import lib as _lib  # noqa: E402
 
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 131040
 if os.environ.get('MG_GEMM_VARIANT'):       # measurement only: 0 = the library's own choice by shape
-    _lib.load().mg_gemm_set_variant(int(os.environ['MG_GEMM_VARIANT']))
+    assert _lib.ab_library().__enter__().mg_gemm_set_variant(int(os.environ['MG_GEMM_VARIANT'])) == 0      # the A/B library, for the whole process
 dev = torch.device('cuda:0')
 g = torch.Generator(device=dev).manual_seed(0)
 
