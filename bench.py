@@ -55,6 +55,63 @@ MODEL_14B = dict(dim=5120, ffn_dim=13824, freq_dim=256, num_heads=40, num_layers
                  in_dim=16, out_dim=16, eps=1e-6)
 
 
+def _telemetry(device_index, period_s=0.5):
+    """tools/gpu_telemetry.py: an in-process thread reading libamd_smi (no child process, nothing on the GPU)"""
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    from gpu_telemetry import GpuTelemetry
+    return GpuTelemetry(device_index=device_index, period_s=period_s)
+
+
+def box_calibration(dev, device_index, secs_attn=6.0, secs_gemm=3.0):
+    """What THIS box sustains on the two hot kernels alone, on fixed random operands, before anything else runs — so that a step time
+    measured on one box can be compared with one measured on another (the same attention kernel ran 228-243 ms per launch on different
+    boxes of one round): self-attention at L = 131 040 x 8 heads (1/5 of a launch of the workload) back to back for `secs_attn` seconds,
+    the ffn.0 GEMM shape (131 040 x 13 824 x 5 120, bias + GELU) for `secs_gemm`, each with clock / power / temperature / firmware
+    violation residencies sampled meanwhile."""
+    from wan.backend import ops
+    out = {}
+    g = torch.Generator(device=dev).manual_seed(1234)
+    L, heads = 131040, 8
+    q = torch.randn(L, heads * 128, device=dev, generator=g).bfloat16()
+    k = torch.randn(L, heads * 128, device=dev, generator=g).bfloat16()
+    v = torch.randn(L, heads * 128, device=dev, generator=g).bfloat16()
+    kp = torch.empty(ops.packed_kv_numel(L, heads), dtype=torch.bfloat16, device=dev)
+    vp = torch.empty_like(kp)
+    o = torch.empty_like(q)
+    ops.pack_kv(k, v, heads, kp, vp)
+
+    def loop(fn, secs, flops):
+        fn()
+        torch.cuda.synchronize()
+        tel = _telemetry(device_index, 0.25).start()
+        ms, n = 0.0, 0
+        while ms < secs * 1e3:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(4):
+                fn()
+            b.record()
+            torch.cuda.synchronize()
+            ms += a.elapsed_time(b)
+            n += 4
+        t = tel.stop()
+        return {'tflops': flops * n / (ms * 1e-3) / 1e12, 'ms_per_launch': ms / n, 'launches': n,
+                **{k_: t[k_] for k_ in ('sclk_mhz_mean', 'power_w_mean', 'temp_c_max', 'residency') if k_ in t}}
+    out['attn'] = loop(lambda: ops.attention_hd128(q, kp, vp, o, L, heads, 1.0, prescaled=True), secs_attn, 4.0 * L * L * 128 * heads)
+    del q, k, v, kp, vp, o
+    N, K = 13824, 5120
+    a_ = torch.randn(L, K, device=dev, generator=g).bfloat16()
+    w_ = (torch.randn(N, K, device=dev, generator=g) * 0.02).bfloat16()
+    b_ = torch.randn(N, device=dev, generator=g)
+    u_ = torch.empty(L, N, dtype=torch.bfloat16, device=dev)
+    out['gemm_ffn0'] = loop(lambda: ops.gemm(a_, w_, b_, ops.BIAS_GELU_BF16, u_), secs_gemm, 2.0 * L * N * K)
+    del a_, w_, b_, u_
+    torch.cuda.empty_cache()
+    out['how'] = ('before the warm-up, this process, random operands: mg_attn_fwd_bf16_hd128_prescaled at L = 131040 x 8 heads and mg_gemm_bf16 '
+                  'at 131040 x 13824 x 5120 (bias + GELU) back to back, HIP events around groups of 4 launches; telemetry = tools/gpu_telemetry.py')
+    return out
+
+
 def flops_per_forward(L, cfg):
     """SURVEY.md §8(d) closed form (== FlopCounterMode on the reference)."""
     d, f, n = cfg['dim'], cfg['ffn_dim'], cfg['num_layers']
@@ -256,6 +313,8 @@ def main():
     ap.add_argument('--no-pmc', action='store_true',
                     help="N = 1: skip the two rocprofv3 --pmc passes that measure the dominant kernel's HBM traffic after the timed "
                          'region (roofline.traffic is then read from the newest committed summary and labelled so)')
+    ap.add_argument('--no-calibration', action='store_true',
+                    help='skip the ~10 s box calibration (attention / GEMM alone on random operands before the warm-up: box_attn_tflops)')
     ap.add_argument('--layers', type=int, default=None, help='debug only: fewer layers (marks the line invalid)')
     ap.add_argument('--gemm-variant', type=int, default=0,
                     help='A/B only: force a tile schedule of mg_gemm_bf16 (same bits; 0 = the library default by shape, 8 = the round-3 '
@@ -308,6 +367,9 @@ def main():
     if args.gemm_variant:
         from wan.backend import lib as _lib
         _lib.ab_library().__enter__().mg_gemm_set_variant(args.gemm_variant)      # measurement only: the whole process runs on the A/B library
+    calib = None
+    if world == 1 and not args.no_calibration and args.workload != 'tiny' and not args.layers:
+        calib = box_calibration(dev, local)
     model = wan.modules.WanModel(**cfg, device=dev)
     model.init_weights(seed=0)
     model.eval().requires_grad_(False)
@@ -381,11 +443,13 @@ def main():
         if args.dit_fsdp:
             BlockShards.trace = []
     recording['on'] = True
+    tel = _telemetry(local).start() if rank == 0 else None        # a thread reading sysfs through libamd_smi twice a second: nothing in the GPU's way
     t0 = time.perf_counter()
     for i in range(args.warmup, total):
         step(i)
     fence()
     elapsed = time.perf_counter() - t0
+    telemetry = tel.stop() if tel is not None else None
     recording['on'] = False
     overlap = rank_devices = fsdp_trace = None
     peer_used = False
@@ -497,6 +561,14 @@ def main():
                          'launches_timed': len(attn_events), 'ms_per_launch': attn_ms,
                          'algorithmic_flops_per_launch': attn_flops},
         }
+        # clock / power / temperature of the timed region and the firmware's own account of what held the clock (PPT = package power
+        # tracking, thermal, VR, HBM, PROCHOT residencies: fraction of the interval each limiter was active), + what this box sustains on
+        # the two hot kernels alone: without them a slow box and a slow build are indistinguishable
+        line['telemetry'] = telemetry
+        if calib is not None:
+            line['box_attn_tflops'] = calib['attn']['tflops']
+            line['box_gemm_tflops'] = calib['gemm_ffn0']['tflops']
+            line['box_calibration'] = calib
         if vae_s is not None:
             fv = vae_decode_flops(*lat_shape[1:])[0]                    # the reference's arithmetic
             fx = vae_decode_flops(*lat_shape[1:], up_taps=4)[0]         # what the MFMAs execute (phase-decomposed up-convs)

@@ -797,10 +797,11 @@ def test_fullsize_attention_big_configs(dev, Lq, Lk, heads):
     _attn_rows_check(q6, k[:lk2], v[:lk2], o, rows, hs, sc)
 
 
-@pytest.mark.parametrize('M', [16380, 32760, 41580, 131040])
+@pytest.mark.parametrize('M', [16380, 32760, 41580, 75600, 131040, 166320])
 def test_fullsize_gemm_big_configs(dev, M):
-    """the four GEMM shapes of a block at the per-rank / single-GPU token counts of configs[2], [3]: 16 380 = L/8 (Ulysses 8),
-    32 760 = L/4 (what `bench.py --gpus 8` runs: CFG halves x Ulysses 4), 41 580 = configs[3]'s L/4, 131 040 = one GPU."""
+    """the four GEMM shapes of a block at the per-rank / single-GPU token counts of configs[1], [2], [3]: 16 380 = L/8 (Ulysses 8),
+    32 760 = L/4 (what `bench.py --gpus 8` runs: CFG halves x Ulysses 4), 41 580 = configs[3]'s L/4, 75 600 = 720p on one GPU,
+    131 040 = 1080p on one GPU, 166 320 = `bench.py --workload 1056p --gpus 1` (N = 13 824 / 15 360: output element index past 2^31)."""
     from wan.backend import ops
     d, f = 5120, 13824
     gen = torch.Generator(device=dev).manual_seed(M % 89)
@@ -825,6 +826,148 @@ def test_fullsize_gemm_big_configs(dev, M):
             ref = torch.nn.functional.gelu(acc, approximate='tanh') if epi == ops.BIAS_GELU_BF16 else acc
             assert ((out[rows].float() - ref).abs().max() / ref.abs().max()).item() < 1e-2
         del a, w
+
+
+def _rope_dev(x, grid, hd, pos0=0):
+    """oracle.dit.rope (reference model.py:39-67) restated for DEVICE tensors: x [rows, N, hd] fp32, token index = pos0 + row, angles from
+    oracle.dit.rope_table in fp64.  (The oracle's own function builds its index tensors on the host; this is the same arithmetic.)"""
+    from oracle import dit
+    f, h, w = grid
+    ta, th, tw = [t.to(x.device) for t in dit.rope_table(hd)]
+    idx = torch.arange(x.shape[0], device=x.device) + pos0
+    fi, hi, wi = idx // (h * w), (idx // w) % h, idx % w
+    ang = torch.cat([ta[fi], th[hi], tw[wi]], dim=-1)                      # [rows, hd/2] fp64
+    xd = x.to(torch.float64).reshape(x.shape[0], x.shape[1], -1, 2)
+    c, s_ = torch.cos(ang)[:, None, :], torch.sin(ang)[:, None, :]
+    a, b = xd[..., 0], xd[..., 1]
+    return torch.stack([a * c - b * s_, a * s_ + b * c], dim=-1).flatten(2).to(torch.float32)
+
+
+@pytest.mark.parametrize('grid', [(21, 52, 120), (21, 66, 120)], ids=['1080p', '1056p'])
+def test_rmsnorm_rope_real_grids(dev, grid):
+    """RoPE at the grids the bench runs: the (f, h, w) decomposition of token indices up to L - 1 and table rows up
+    to w = 119 / h = 65 / f = 20, against oracle.dit.rope itself — slices of 64 rows at the start, across a frame boundary, across a row
+    boundary and at the very end (pos0 = L - 64), and the device restatement used by the block test below against the oracle too."""
+    from oracle import dit
+    from wan.backend import ops
+    from wan.modules.model import rope_cos_sin
+    dim, hd = 5120, 128
+    f, h, w = grid
+    L = f * h * w
+    tab = rope_cos_sin(hd, grid).to(dev)
+    wt = 1 + 0.1 * W.randn((dim,), 5)
+    for pos0 in (0, h * w - 32, 7 * h * w + 3 * w - 32, L // 2 + 17, L - 64):
+        x = (W.randn((64, dim), 4 + pos0 % 7) * 2).bfloat16()
+        ref = dit.rope(dit.rmsnorm(x.float(), wt, 1e-6, True).view(64, dim // hd, hd), grid, dit.rope_table(hd, max_len=1024), pos0)
+        out = torch.empty(64, dim, dtype=torch.bfloat16, device=dev)
+        ops.rmsnorm_rope(x.to(dev), wt.to(dev), 1e-6, hd, out, tab, grid, pos0)
+        assert scale_err(out.float(), ref.reshape(64, dim).bfloat16().float()) < 1e-2, pos0
+        mine = _rope_dev(dit.rmsnorm(x.float(), wt, 1e-6, True).view(64, dim // hd, hd).to(dev), grid, hd, pos0).cpu()
+        assert (mine - ref).abs().max().item() < 1e-5, pos0
+
+
+def test_fullsize_rowwise_kernels_past_2gib(dev):
+    """mg_ln_modulate / mg_gate_residual_f32 / mg_rmsnorm_rope_bf16 on a buffer of L = 166 320 rows (the fp32 residual stream is 3.4 GB:
+    byte offsets pass 2^31 at row 104 857 and 2^32 would be row 209 715): rows at the start, around the 2^31-byte boundary and the last
+    64 against the oracle (the largest row count tested was 300)."""
+    from oracle import dit
+    from wan.backend import ops
+    from wan.modules.model import rope_cos_sin
+    L, d, hd, grid = 166320, 5120, 128, (21, 66, 120)
+    gen = torch.Generator(device=dev).manual_seed(7)
+    x = torch.randn(L, d, device=dev, generator=gen) * 2
+    sc, sh = torch.randn(d, device=dev, generator=gen), torch.randn(d, device=dev, generator=gen)
+    rows = torch.cat([torch.arange(0, 4), torch.arange(104855, 104861), torch.arange(L - 64, L)]).to(dev)
+    hb = torch.empty(L, d, dtype=torch.bfloat16, device=dev)
+    ops.ln_modulate(x, sc, sh, True, 1e-6, hb)
+    ref = (dit.layernorm(x[rows].cpu(), 1e-6) * (1 + sc.cpu()) + sh.cpu()).bfloat16().float()
+    assert scale_err(hb[rows].float(), ref) < 1e-2
+    hf = torch.empty(L, d, dtype=torch.float32, device=dev)
+    ops.ln_modulate(x, sc, sh, False, 1e-6, hf)
+    assert scale_err(hf[rows], dit.layernorm(x[rows].cpu(), 1e-6, sc.cpu(), sh.cpu())) < 1e-5
+    del hf
+    # x += y * gate on every row, exact (one product, one sum per element, as torch's two kernels)
+    y = torch.randn(L, d, device=dev, generator=gen).bfloat16()
+    x0 = x[rows].clone()
+    ops.gate_residual(x, y, sc)
+    assert torch.equal(x[rows], x0 + y[rows].float() * sc)
+    # RMS-norm + RoPE in place of q at the last rows of the 1056p grid
+    wq = 1 + 0.1 * torch.randn(d, device=dev, generator=gen)
+    out = torch.empty(L, d, dtype=torch.bfloat16, device=dev)
+    ops.rmsnorm_rope(y, wq, 1e-6, hd, out, rope_cos_sin(hd, grid).to(dev), grid, 0)
+    for r0 in (104855, L - 64):
+        ref = dit.rope(dit.rmsnorm(y[r0:r0 + 6].float().cpu(), wq.cpu(), 1e-6, True).view(6, d // hd, hd), grid, dit.rope_table(hd), r0)
+        assert scale_err(out[r0:r0 + 6].float(), ref.reshape(6, d).bfloat16().float()) < 1e-2, r0
+
+
+def test_fullsize_block_composition_vs_fp32(dev):
+    """ONE WanAttentionBlock at the metric's shape through the engine — L = 131 040 tokens of the (21, 52, 120) grid, d = 5120, 40 heads,
+    ffn 13 824, 512 text keys: LN-modulate -> q|k|v GEMM -> RMS-norm + RoPE -> pack -> attention -> o-proj + gate -> cross-attention -> FFN —
+    and, for 16 sampled token rows (first / last, 256-row tile edges, frame and grid-row boundaries), an fp32 torch evaluation IN THIS TEST
+    of the same block from the block's own input (reference model.py:274-313; K / V of all tokens by torch matmuls on the GPU).  The pieces
+    are checked at this size elsewhere; this is their composition.  Tolerance: the stated 2e-2 of the largest
+    reference value, on the block's UPDATE (x_out - x_in: the residual stream itself would hide an error 30 times larger)."""
+    import wan
+    from oracle import dit
+    from wan.backend import ops
+    cfg = dict(model_type='t2v', patch_size=(1, 2, 2), text_len=512, in_dim=16, dim=5120, ffn_dim=13824, freq_dim=256, text_dim=4096,
+               out_dim=16, num_heads=40, num_layers=1, eps=1e-6)
+    grid, d, N, hd = (21, 52, 120), 5120, 40, 128
+    L = grid[0] * grid[1] * grid[2]
+    model = wan.modules.WanModel(**cfg, device=dev)
+    model.init_weights(seed=3)
+    model.eval().requires_grad_(False)
+    gen = torch.Generator(device=dev).manual_seed(11)
+    lat = torch.randn(16, 21, 104, 240, device=dev, generator=gen)
+    ctx = torch.randn(512, 4096, device=dev, generator=gen).bfloat16()
+    captured = {}
+    orig = ops.ln_modulate
+
+    def spy(x, *a, **k):
+        if 'x_in' not in captured:
+            captured['x_in'] = x.clone()                 # the block's input, exactly as the engine sees it
+        return orig(x, *a, **k)
+    ops.ln_modulate = spy
+    try:
+        model([lat], t=torch.tensor([500], device=dev), context=[ctx], seq_len=L)
+    finally:
+        ops.ln_modulate = orig
+    ws = next(iter(model._ws.values()))
+    x_in, x_out = captured['x_in'], ws['x']              # (the head reads x, it does not write it)
+    assert x_in.shape == (L, d) and torch.isfinite(x_out).all().item()
+    e = ws['mod'][:6].float()                            # blocks.0.modulation + e0, as the engine applied it
+    ctx_emb = model._context(ctx)[1].float()             # the text embedding the engine's cross-attention used
+    P = {k: v.float() for k, v in model.state_dict().items() if k.startswith('blocks.0.')}
+    pre, sa, ca = 'blocks.0.', 'blocks.0.self_attn.', 'blocks.0.cross_attn.'
+    rows = torch.tensor([0, 1, 119, 120, 255, 256, 6239, 6240, 6240 * 7 + 120 * 31 + 5, 65535, 65536, L // 2, L - 257, L - 256, L - 2, L - 1],
+                        device=dev)
+    lin = lambda x, n: dit.linear(x, P[n + '.weight'], P[n + '.bias'], False)
+    # self-attention: K / V for ALL tokens (fp32 matmuls on the device), q and everything behind it for the sampled rows
+    h = dit.layernorm(x_in, 1e-6) * (1 + e[1]) + e[0]
+    k = _rope_dev(dit.rmsnorm(lin(h, sa + 'k'), P[sa + 'norm_k.weight'], 1e-6, False).view(L, N, hd), grid, hd)
+    v = lin(h, sa + 'v').view(L, N, hd)
+    qs = dit.rmsnorm(lin(h[rows], sa + 'q'), P[sa + 'norm_q.weight'], 1e-6, False).view(-1, N, hd)
+    qs = torch.cat([_rope_dev(qs[i:i + 1], grid, hd, int(rows[i])) for i in range(rows.numel())])
+    del h
+    a = dit.attention(qs, k, v, L, False)                # [16, N, hd]: 16 x 131 040 scores per head
+    del k, v
+    x = x_in[rows] + lin(a.reshape(-1, d), sa + 'o') * e[2]
+    # cross-attention over the 512 text keys
+    hq = dit.layernorm(x, 1e-6, P[pre + 'norm3.weight'], P[pre + 'norm3.bias'])
+    q = dit.rmsnorm(lin(hq, ca + 'q'), P[ca + 'norm_q.weight'], 1e-6, False)
+    kc = dit.rmsnorm(lin(ctx_emb, ca + 'k'), P[ca + 'norm_k.weight'], 1e-6, False)
+    vc = lin(ctx_emb, ca + 'v')
+    a = dit.attention(q.view(-1, N, hd), kc.view(-1, N, hd), vc.view(-1, N, hd), kc.shape[0], False)
+    x = x + lin(a.reshape(-1, d), ca + 'o')
+    # ffn
+    hf = dit.layernorm(x, 1e-6) * (1 + e[4]) + e[3]
+    u = torch.nn.functional.gelu(lin(hf, pre + 'ffn.0'), approximate='tanh')
+    ref = x + lin(u, pre + 'ffn.2') * e[5]
+    upd_ref, upd = ref - x_in[rows], x_out[rows] - x_in[rows]
+    err = ((upd - upd_ref).abs().max() / upd_ref.abs().max()).item()
+    assert err < 2e-2, err
+    # and no row of the 131 040 was skipped: the update is non-zero everywhere
+    assert ((x_out - x_in).abs().amax(dim=1) > 0).all().item()
 
 
 def _conv_ref_f64(x, cache, w, bias, pts, up2=False):
