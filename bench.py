@@ -451,7 +451,7 @@ def main():
     elapsed = time.perf_counter() - t0
     telemetry = tel.stop() if tel is not None else None
     recording['on'] = False
-    overlap = rank_devices = fsdp_trace = None
+    overlap = rank_devices = fsdp_trace = sp_groups = None
     peer_used = False
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -460,6 +460,9 @@ def main():
         overlap = HeadExchange.overlap_summary()
         HeadExchange.trace = None
         peer_used = any('xchg' in w_ and w_['xchg'].peer is not None for w_ in model._ws.values())
+        xchgs = [w_['xchg'] for w_ in model._ws.values() if 'xchg' in w_]
+        sp_groups = {'heads_per_group': [n for _, n in xchgs[0].groups], 'attention_rounds_per_layer': xchgs[0].rounds,
+                     'chosen_by': os.environ.get('MOVIIGEN_SP_GROUPS', 'auto')} if xchgs else None
         if args.dit_fsdp:
             from wan.distributed.collectives import trace_summary
             fsdp_trace = trace_summary(BlockShards.trace)
@@ -622,7 +625,7 @@ def main():
                 line['vae_decode_layout'] = f'layer pipeline over {world} ranks (WanVAE.decode_pipelined)' if vae_pipe else 'rank 0 alone (reference text2video.py:260-261)'
             if overlap and overlap['collectives']:
                 per = 1.0 / args.steps
-                line['overlap'] = {'exchange_ms_per_step': overlap['exchange_ms'] * per, 'exposed_ms_per_step': overlap['exposed_ms'] * per,
+                line['overlap'] = {'groups': sp_groups, 'exchange_ms_per_step': overlap['exchange_ms'] * per, 'exposed_ms_per_step': overlap['exposed_ms'] * per,
                                    'hidden_frac': overlap['hidden_frac'], 'collectives_per_step': overlap['collectives'] * per,
                                    'how': 'rank 0: timing events around every all-to-all on the comm stream (exchange) and around every '
                                           'wait of the compute stream on the comm stream (exposed); hidden = 1 - exposed / exchange'}

@@ -52,6 +52,38 @@ def split_heads(n_loc, max_groups):
     return out
 
 
+def attention_rounds(n_heads, L, n_cu=256, qblock=256):
+    """rounds ONE launch of the persistent head-dim-128 kernel takes for `n_heads` heads over L queries: heads x ceil(L / 256) items of
+    one 256-query block each, dealt to the 8 XCDs in contiguous ranges and walked by the n_cu / 8 workgroups of an XCD in rounds
+    (csrc/attn_hd128_m16.hip: the work loop).  A round lasts as long as one item whatever the number of busy workgroups."""
+    items = n_heads * ((L + qblock - 1) // qblock)
+    per_xcd_wg = max(1, (n_cu & ~7) // 8)
+    if items <= (n_cu & ~7):
+        return 1
+    return max(((x + 1) * items // 8 - x * items // 8 + per_xcd_wg - 1) // per_xcd_wg for x in range(8))
+
+
+def choose_groups(n_loc, L, P, dim=None, max_groups=5, n_cu=256, tflops_per_cu=5.8, link_gbps=45.0):
+    """How many pipeline groups the rank's n_loc heads are cut into (a fixed 5 ignored the round quantisation of
+    the persistent attention grid — five 2-head groups of configs[3] take 6 rounds per launch for 5.08 rounds of work, -15 %).
+    Cost of a layer with G groups = sum over the groups of attention_rounds(n_g) x (time of one 256-query item over L keys)
+                                   + the part of the exchange no attention can hide: the first group's q|k|v exchange and the last group's
+                                     return = 1 / G of the layer's exchange (4 * (L / P) * dim * 2 bytes / P per link);
+    the smallest cost wins, ties go to MORE groups.  With the exchange term small this is "fewest rounds, then most groups".
+    -> (G, rounds, cost_ms): e.g. configs[2] (L = 131 040, 5 local heads): 5 groups, 10 rounds; configs[3] (L = 166 320, cfg2 x SP4, 10
+    local heads): 2 groups of 5 heads, 26 rounds (5 x 2 heads: 30); 720p x SP8 (5 heads, 296 query blocks): ONE group, 6 rounds (5 x 1: 10)."""
+    dim = dim if dim is not None else 128 * n_loc * P
+    t_item = 4.0 * 256 * L * 128 / (tflops_per_cu * 1e12) * 1e3                      # ms
+    t_exch = 4.0 * (L / P) * dim * 2 / P / (link_gbps * 1e9) * 1e3 if P > 1 else 0.0   # ms per layer on one link (all links concurrent)
+    best = None
+    for G in range(1, max(1, min(int(n_loc), int(max_groups))) + 1):
+        rounds = sum(attention_rounds(n, L, n_cu) for _, n in split_heads(n_loc, G))
+        cost = rounds * t_item + t_exch / G
+        if best is None or cost < best[2] - 1e-9 or (abs(cost - best[2]) <= 1e-9 and G > best[0]):
+            best = (G, rounds, cost)
+    return best
+
+
 class HeadExchange:
     """persistent buffers, events and the communication stream of the pipelined exchange for one
     (group, Lloc) shape.  `run(q, k, v, out, attend)` executes one layer's exchange + attention.
@@ -80,12 +112,18 @@ class HeadExchange:
     def __init__(self, group, P, heads, head_dim, Lloc, device, max_groups=None):
         if heads % P:
             raise ValueError(f'`num_heads` {heads} cannot be divided evenly by the sequence-parallel size {P}')
-        if max_groups is None:
-            max_groups = int(os.environ.get('MOVIIGEN_SP_GROUPS', '5'))
         self.group, self.P, self.hd, self.Lloc = group, P, head_dim, Lloc
         self.n_loc = heads // P
         self.cols = self.n_loc * head_dim                      # columns of one destination's head slice
+        if max_groups is None:
+            env = os.environ.get('MOVIIGEN_SP_GROUPS', 'auto')
+            if env == 'auto':                                  # by shape: rounds of the persistent attention grid vs exposed exchange
+                n_cu = torch.cuda.get_device_properties(device).multi_processor_count if torch.device(device).type == 'cuda' else 256
+                max_groups = choose_groups(self.n_loc, P * Lloc, P, dim=heads * head_dim, n_cu=n_cu)[0] if head_dim == 128 else min(5, self.n_loc)
+            else:
+                max_groups = int(env)
         self.groups = split_heads(self.n_loc, max_groups)
+        self.rounds = sum(attention_rounds(n, P * Lloc) for _, n in self.groups)
         bf = torch.bfloat16
         e = lambda *s: torch.empty(*s, dtype=bf, device=device)  # noqa: E731
         self.send, self.recv, self.ag, self.orecv = [], [], [], []

@@ -417,3 +417,23 @@ def test_gemm_v11_schedule_is_the_generators_output(tmp_path):
     assert names == ['gemm_bf16_v11_ktile_s4.inc', 'gemm_bf16_v11_ktile_s6.inc', 'gemm_bf16_v11_tail.inc']
     for n in names:
         assert open(os.path.join(tmp_path, n)).read() == open(os.path.join(ROOT, 'moviigen1.1_amd', 'csrc', n)).read(), n
+
+
+def test_sp_group_chooser_on_the_baseline_shapes():
+    """the Ulysses pipeline depth follows the shape: rounds of the persistent attention grid per layer, then exposed
+    exchange; the four BASELINE multi-GPU shapes + the published-reference case (720p x 8 GPUs)."""
+    from wan.distributed.ulysses import attention_rounds, choose_groups, split_heads
+    rounds = lambda n, L, G: sum(attention_rounds(m, L) for _, m in split_heads(n, G))
+    # configs[2]: 1920x832, Ulysses 8 -> 5 local heads, 512 query blocks: every split takes 10 rounds, so the deepest pipeline
+    assert choose_groups(5, 131040, 8)[:2] == (5, 10)
+    # configs[3]: 1920x1056, cfg2 x Ulysses 4 -> 10 local heads, 650 query blocks: 5 x 2 heads = 6 rounds per launch for 5.08 of work
+    assert rounds(10, 166320, 5) == 30 and rounds(10, 166320, 2) == 26 and rounds(10, 166320, 1) == 26
+    assert choose_groups(10, 166320, 4)[:2] == (2, 26)
+    # what `bench.py --gpus 8` runs by default (1080p, cfg2 x Ulysses 4): 1024 items per 2-head launch = 4 full rounds
+    assert choose_groups(10, 131040, 4)[:2] == (5, 20)
+    # the published-reference case, 1280x720 on 8 GPUs: a 1-head launch has 296 items = 2 rounds for 1.16 of work -> one launch of 5 heads
+    assert rounds(5, 75600, 5) == 10 and choose_groups(5, 75600, 8)[:2] == (1, 6)
+    # single rank: nothing to exchange, nothing to pipeline over
+    assert attention_rounds(40, 131040) == 80 and attention_rounds(1, 300) == 1
+    # the explicit setting still wins (HeadExchange reads MOVIIGEN_SP_GROUPS) and sizes differ by at most one
+    assert [n for _, n in split_heads(10, 4)] == [3, 3, 2, 2]
