@@ -313,6 +313,9 @@ def main():
     ap.add_argument('--no-pmc', action='store_true',
                     help="N = 1: skip the two rocprofv3 --pmc passes that measure the dominant kernel's HBM traffic after the timed "
                          'region (roofline.traffic is then read from the newest committed summary and labelled so)')
+    ap.add_argument('--emulate-rank', type=int, default=0, metavar='P',
+                    help='no measurement of this box: ONE rank of a P-GPU run emulated on one GPU (tools/emulate_rank.py: the real engine on '
+                         'loop-back process groups, per-rank shapes, real message sizes); prints lines marked `invalid: emulation`')
     ap.add_argument('--no-calibration', action='store_true',
                     help='skip the ~10 s box calibration (attention / GEMM alone on random operands before the warm-up: box_attn_tflops)')
     ap.add_argument('--layers', type=int, default=None, help='debug only: fewer layers (marks the line invalid)')
@@ -320,6 +323,10 @@ def main():
                     help='A/B only: force a tile schedule of mg_gemm_bf16 (same bits; 0 = the library default by shape, 8 = the round-3 '
                          'default); recorded in config.gemm_variant')
     args = ap.parse_args()
+    if args.emulate_rank:
+        cmd = [sys.executable, os.path.join(ROOT, 'tools', 'emulate_rank.py'), '--workload', args.workload if args.workload in ('720p', '1080p', '1056p') else '1080p',
+               '--ranks', str(args.emulate_rank), '--steps', str(args.steps), '--fsdp-at'] + ([str(args.emulate_rank)] if args.dit_fsdp else [])
+        os.execv(sys.executable, cmd)
     if args.transport is not None:        # read by wan.distributed at exchange-construction time; inherited by self-launched ranks
         os.environ['MOVIIGEN_SP_TRANSPORT'] = '' if args.transport == 'torch' else args.transport
 

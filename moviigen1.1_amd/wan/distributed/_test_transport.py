@@ -7,17 +7,41 @@ import torch
 import torch.distributed as dist
 
 
+class EmulatedGroup:
+    """MEASUREMENT ONLY (tools/emulate_rank.py, `bench.py --emulate-rank`): stands for a process group of `size` ranks of which only THIS
+    process exists — a single-GPU box predicting what one rank of a multi-GPU run does.  Every collective on it is a LOOP-BACK: device
+    copies of the real message sizes on the calling stream (the peers' data is this rank's own, repeated), and the bytes that would have
+    crossed a link are counted.  The numbers such a run prints are marked `invalid: emulation`; nothing in a real launch creates one."""
+
+    def __init__(self, size, rank=0, name='emulated'):
+        self.size, self.rank, self.name = int(size), int(rank), name
+        self.link_bytes = {'all_to_all': 0, 'all_gather': 0}      # bytes this rank would send over ONE of its P - 1 links
+        self.calls = {'all_to_all': 0, 'all_gather': 0}
+
+    def _count(self, kind, total_bytes):
+        self.calls[kind] += 1
+        self.link_bytes[kind] += total_bytes // self.size           # 1 / P of the buffer goes to each peer, each over its own link
+
+
 def staged(t, group):
+    if isinstance(group, EmulatedGroup):
+        return True
     return t.is_cuda and dist.get_backend(group) == 'gloo'
 
 
 def all_to_all(recv, send, group):
+    if isinstance(group, EmulatedGroup):
+        recv.view(-1).copy_(send.reshape(-1))                      # chunk p <- "rank p's" chunk = my own
+        return group._count('all_to_all', send.numel() * send.element_size())
     s, r = send.cpu(), torch.empty(recv.shape, dtype=recv.dtype)
     dist.all_to_all_single(r, s, group=group)
     recv.copy_(r)
 
 
 def all_gather(out, x, group):
+    if isinstance(group, EmulatedGroup):
+        out.view(group.size, -1).copy_(x.reshape(1, -1).expand(group.size, -1))
+        return group._count('all_gather', x.numel() * x.element_size() * group.size)
     P = dist.get_world_size(group)
     parts = [torch.empty(x.shape, dtype=x.dtype) for _ in range(P)]
     dist.all_gather(parts, x.cpu().contiguous(), group=group)
@@ -25,6 +49,8 @@ def all_gather(out, x, group):
 
 
 def broadcast(t, src, group):
+    if isinstance(group, EmulatedGroup):
+        return
     h = t.cpu()
     dist.broadcast(h, src=src, group=group)
     t.copy_(h)
@@ -59,5 +85,7 @@ class RingHop:
 
 
 def rendezvous(group):
+    if isinstance(group, EmulatedGroup):
+        return
     torch.cuda.current_stream().synchronize()
     dist.barrier(group=group)
