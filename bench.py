@@ -307,7 +307,7 @@ def main():
     ap.add_argument('--vae-parallel', action='store_true',
                     help='N > 1: the VAE decode of the sec/video tail as the layer-pipelined decode over all ranks '
                          '(WanVAE.decode_pipelined) instead of rank 0 alone as in the reference (text2video.py:260-261)')
-    ap.add_argument('--transport', default=None, choices=['torch', 'rccl_direct', 'peer_copy'],
+    ap.add_argument('--transport', default=None, choices=['auto', 'torch', 'rccl_direct', 'peer_copy'],
                     help='N > 1: transport of the Ulysses exchange — torch.distributed nccl (default), the C-ABI collectives on the '
                          "library's own RCCL communicator, or one-sided peer copies on the copy engines")
     ap.add_argument('--no-pmc', action='store_true',
@@ -328,7 +328,7 @@ def main():
                '--ranks', str(args.emulate_rank), '--steps', str(args.steps), '--fsdp-at'] + ([str(args.emulate_rank)] if args.dit_fsdp else [])
         os.execv(sys.executable, cmd)
     if args.transport is not None:        # read by wan.distributed at exchange-construction time; inherited by self-launched ranks
-        os.environ['MOVIIGEN_SP_TRANSPORT'] = '' if args.transport == 'torch' else args.transport
+        os.environ['MOVIIGEN_SP_TRANSPORT'] = args.transport
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # plain `python bench.py --gpus N`: become the launcher of N ranks (the driver's torchrun form skips this)
@@ -615,7 +615,7 @@ def main():
             line['rank_devices'] = rank_devices
             # what the exchange objects REALLY use (a peer-copy request falls back to the collective when the IPC mapping fails)
             line['transport'] = {
-                'requested': args.transport or os.environ.get('MOVIIGEN_SP_TRANSPORT') or 'torch',
+                'requested': args.transport or os.environ.get('MOVIIGEN_SP_TRANSPORT') or 'auto',
                 'used': ('gloo through host memory (test plumbing)' if gloo else
                          'one-sided peer copies (hipMemcpyAsync D2D into IPC-mapped receive buffers) between two flag all-reduces' if peer_used else
                          "C-ABI collectives on the library's RCCL communicator (mg_sp_all_to_all: grouped ncclSend/ncclRecv)"

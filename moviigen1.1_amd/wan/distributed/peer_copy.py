@@ -26,8 +26,57 @@ import torch.distributed as dist
 from . import collectives
 
 
+def mode():
+    """MOVIIGEN_SP_TRANSPORT: 'auto' (default) | 'peer_copy' | 'torch' | 'rccl_direct'"""
+    return os.environ.get('MOVIIGEN_SP_TRANSPORT', '') or 'auto'
+
+
 def enabled():
-    return os.environ.get('MOVIIGEN_SP_TRANSPORT', '') == 'peer_copy'
+    return mode() == 'peer_copy'
+
+
+def wanted(group, device):
+    """does a HeadExchange on `group` try the copy-engine transport?  Always when it is asked for by name; in `auto` mode when the group
+    runs on RCCL with more than one rank on device buffers — i.e. on a real multi-GPU launch: the copy engines move the bytes there and the
+    persistent attention grid keeps every CU (a kernel transport only runs once an attention launch has ended).  A window that
+    cannot be opened on every rank, or that fails its self-check, leaves the exchange on the collective (logged, `transport.used` says so)."""
+    if torch.device(device).type != 'cuda' or group is None:
+        return False
+    if mode() == 'peer_copy':
+        return True
+    if mode() != 'auto':
+        return False
+    try:
+        return dist.get_backend(group) == 'nccl' and dist.get_world_size(group) > 1
+    except Exception:      # noqa: BLE001 — not a torch.distributed group (the rank emulation): the collective path
+        return False
+
+
+def self_check(win, group, buffer_index=0):
+    """ONE exchange of a known pattern through the windows, before the first real one: chunk p of rank r's send image carries the value
+    1000 r + p, so slot s of MY buffer must read 1000 s + my rank.  All ranks or none: a mismatch anywhere (a mapping that opened but does
+    not reach the right memory) sends the whole group back to the collective.  -> win or None"""
+    import logging
+    buf = win.local[buffer_index]
+    P, r = win.P, win.rank
+    keep = buf.clone()
+    send = torch.empty((P,) + tuple(buf.view(P, -1).shape[1:]), dtype=buf.dtype, device=buf.device)
+    for p in range(P):
+        send[p].fill_(float((7 * r + p) % 251))          # exact in bf16
+    win.all_to_all(buffer_index, send)
+    got = buf.view(P, -1)
+    want = torch.tensor([float((7 * s_ + r) % 251) for s_ in range(P)], dtype=torch.float32, device=buf.device)
+    ok = int(torch.equal(got.float(), want[:, None].expand_as(got)))
+    buf.copy_(keep)
+    flag = torch.tensor([ok], dtype=torch.int32, device=buf.device)
+    g = win.group
+    if dist.get_backend(g) == 'gloo':
+        flag = flag.cpu()
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=g)
+    if int(flag.item()) != 1:
+        logging.warning('peer-copy transport: the self-check exchange did not arrive intact on every rank; falling back to the all-to-all collective')
+        return None
+    return win
 
 
 def open_windows(group, buffers):
@@ -48,7 +97,9 @@ def open_windows(group, buffers):
     if dist.get_backend(g) == 'gloo':
         flag = flag.cpu()
     dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=g)           # all ranks or none
-    return win if int(flag.item()) == 1 else None
+    if int(flag.item()) != 1:
+        return None
+    return self_check(win, g)
 
 
 class PeerWindows:

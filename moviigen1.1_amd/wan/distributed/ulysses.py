@@ -24,9 +24,10 @@ the layer becomes a software pipeline over them —
     On the fully connected xGMI mesh an all-to-all sends each peer its 1/P slice over its own direct
     link, all 7 links concurrently.  Tokens are sharded contiguously: rank r owns [r*L/P, (r+1)*L/P).
 
-Transports of the exchange: torch.distributed backend "nccl" (= RCCL; default), the library's own RCCL communicator
-(MOVIIGEN_SP_TRANSPORT=rccl_direct: C-ABI mg_sp_all_to_all) or one-sided peer copies on the copy engines
-(MOVIIGEN_SP_TRANSPORT=peer_copy: peer_copy.py) — the calls themselves live in collectives.py (device to device; the
+Transports of the exchange (MOVIIGEN_SP_TRANSPORT): `auto` (default) = one-sided peer copies on the copy engines (peer_copy.py) when the
+group runs on RCCL with more than one rank AND the peers' buffers can be mapped and pass a pattern exchange on every rank, else
+torch.distributed backend "nccl" (= RCCL) — which `torch` selects by name; `rccl_direct` = the library's own RCCL communicator (C-ABI
+mg_sp_all_to_all); `peer_copy` = the copy engines or a logged fall-back — the calls themselves live in collectives.py (device to device; the
 host-staged gloo transport of the one-GPU multi-process tests is behind its single guard there).  `seq_to_head` /
 `head_to_seq` keep the one-tensor call shape of the reference libraries (used by the training-side SP forward and tests).
 """
@@ -133,10 +134,11 @@ class HeadExchange:
             self.recv.append(e(P * Lloc, 3 * w))
             self.ag.append(e(P * Lloc, w))
             self.orecv.append(e(P, Lloc, w))
-        # MOVIIGEN_SP_TRANSPORT=peer_copy: the receive buffers are mapped into the peers once; an exchange is then P
-        # one-sided device copies on the comm stream (copy engines, no CUs) between two 4-byte rendezvous
+        # The copy-engine transport (MOVIIGEN_SP_TRANSPORT=auto, the default, on an RCCL group of more than one rank; or =peer_copy): the
+        # receive buffers are mapped into the peers once, checked with one pattern exchange, and an exchange is then P one-sided device
+        # copies on the comm stream (copy engines, no CUs) between two 4-byte rendezvous
         self.peer = None
-        if peer_copy.enabled() and self.recv[0].is_cuda and group is not None:
+        if peer_copy.wanted(group, device):
             self.peer = peer_copy.open_windows(group, self.recv + self.orecv)      # None (logged) when IPC mapping is unavailable
         self.comm = torch.cuda.Stream(device=device)
         # CUs the attention launches of this layer leave free while exchanges are in flight (ops.attention_hd128

@@ -1302,6 +1302,7 @@ def _run_hybrid(world, backend, layout, port, transport='torch', model=None):
     env = dict(os.environ, MOVIIGEN_TEST_BACKEND=backend, MOVIIGEN_TEST_LAYOUT=layout, HSA_ENABLE_IPC_MODE_LEGACY='0')
     if model:
         env['MOVIIGEN_TEST_MODEL'] = model
+    env['MOVIIGEN_SP_TRANSPORT'] = 'torch'
     if transport != 'torch':            # rccl_direct: the C-ABI collectives on the library's own communicator
         env['MOVIIGEN_SP_TRANSPORT'] = transport        # (mg_sp_all_to_all, ...); peer_copy: one-sided copies into IPC-mapped buffers
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={world}',
@@ -1340,7 +1341,14 @@ def test_peer_copy_transport_one_gpu():
     _run_hybrid(2, 'gloo', 'sp_fsdp', 29671, 'peer_copy')
 
 
-@pytest.mark.parametrize('transport', ['torch', 'rccl_direct', 'peer_copy'])
+def test_peer_copy_transport_eight_ranks_real_heads_one_gpu():
+    """the copy-engine transport at the REAL rank count: 8 processes sharing cuda:0 map each other's 10 receive
+    buffers (IPC handles among 8 ranks, the pattern self-check, the ring order of the copies), 40 heads on 8 ranks = five one-head
+    pipeline groups, Ulysses 8 + block shards — bit-identical to the unsharded forward at every pipeline depth."""
+    _run_hybrid(8, 'gloo', 'sp_fsdp', 29673, 'peer_copy', model='width40')
+
+
+@pytest.mark.parametrize('transport', ['auto', 'torch', 'rccl_direct', 'peer_copy'])
 @pytest.mark.parametrize('layout', ['cfg_sp_fsdp', 'sp_fsdp'])
 def test_rccl_multi_gpu(layout, transport):
     """the production transport with MORE than one rank: backend nccl (= RCCL over xGMI), one rank per visible GPU
@@ -1349,7 +1357,7 @@ def test_rccl_multi_gpu(layout, transport):
     if n < 2:
         pytest.skip('needs >= 2 GPUs (RCCL refuses two ranks on one device)')
     world = 8 if n >= 8 else 4 if n >= 4 else 2
-    _run_hybrid(world, 'nccl', layout, 29630 + world + {'torch': 0, 'rccl_direct': 20, 'peer_copy': 40}[transport], transport)
+    _run_hybrid(world, 'nccl', layout, 29630 + world + {'torch': 0, 'rccl_direct': 20, 'peer_copy': 40, 'auto': 60}[transport], transport)
 
 
 def test_train_side_sp_forward_one_gpu():
