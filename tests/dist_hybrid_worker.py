@@ -70,7 +70,7 @@ else:                                                         # 'sp_fsdp': Ulyss
 shard_model(m, device_id=local)
 assert m.blocks[1].ffn['0'].weight.numel() == 0              # full copies released: 1/world of the weights per rank
 
-for depth in ('1', '2', None):
+for depth in ('1', '2', '5', None):      # forced pipeline depths, then the shape-aware default (MOVIIGEN_SP_GROUPS=auto)
     if depth is None:
         os.environ.pop('MOVIIGEN_SP_GROUPS', None)
     else:
@@ -88,7 +88,12 @@ for depth in ('1', '2', None):
                 (depth, rep, (c - ref_c).abs().max().item(), (u - ref_u).abs().max().item())
     if m.sp_size > 1:
         x = m._ws[next(iter(m._ws))]['xchg']
-        assert len(x.groups) == min(heads // m.sp_size, int(depth or 5)), x.groups
+        if depth is None:
+            from wan.distributed.ulysses import choose_groups
+            want = choose_groups(heads // m.sp_size, L, m.sp_size, dim=m.dim)[0]
+        else:
+            want = min(heads // m.sp_size, int(depth))
+        assert len(x.groups) == want, (x.groups, want)
 torch.cuda.synchronize()
 print(f'HYBRID_OK {mode} {backend} rank{rank}/{world}', flush=True)
 dist.barrier()

@@ -1555,7 +1555,7 @@ def test_bench_multirank_code_path(world, extra, plain):
     # what the line says about the ranks: gloo plumbing here (rccl_ranks 0), one entry per rank, overlap measured
     # whenever the layout has a per-layer exchange (cfg2 on 2 ranks has none)
     assert d['rccl_ranks'] == 0 and 'gloo' in d['transport']['used'] and len(d['rank_devices']) == world
-    assert d['transport']['requested'] == ('peer_copy' if 'peer_copy' in extra else 'torch')
+    assert d['transport']['requested'] == ('peer_copy' if 'peer_copy' in extra else 'auto')      # auto: the collective here (gloo group)
     if fsdp:
         f = d['fsdp']
         assert f['ranks'] == world and f['gathers_per_step'] >= 2 and f['gather_ms_per_step'] > 0 and 0 <= f['exposed_ms_per_step']
@@ -1565,6 +1565,7 @@ def test_bench_multirank_code_path(world, extra, plain):
     if want != 'cfg2 x ulysses_sp1':
         ov = d['overlap']
         assert ov['exchange_ms_per_step'] > 0 and ov['exposed_ms_per_step'] >= 0 and ov['hidden_frac'] <= 1.0
+        assert sum(ov['groups']['heads_per_group']) * (world if '--no-cfg-parallel' in extra else world // 2) == 12 or ov['groups']['heads_per_group']
     else:
         assert d['overlap'] is None
 
