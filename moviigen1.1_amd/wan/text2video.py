@@ -180,21 +180,27 @@ class WanT2V:
                     self.model.cpu()
                     torch.cuda.empty_cache()
                     offloaded = True
-            if self.vae_parallel:    # layer-pipelined decode over all ranks, video assembled on rank 0
-                videos = self.vae.decode_pipelined(x0)
-                videos = videos if self.rank == 0 else None
-            else:
-                try:
-                    videos = self.vae.decode(x0) if self.rank == 0 else None
-                except torch.cuda.OutOfMemoryError:
-                    if not offload_model or offloaded:
-                        raise
-                    logging.warning('offload_model: the VAE decode ran out of memory beside the resident DiT -> moving the '
-                                    'DiT to the host (reference text2video.py:257-259) and decoding again')
-                    self.model.cpu()
-                    torch.cuda.empty_cache()
-                    offloaded = True
-                    videos = self.vae.decode(x0)
+            def decode():
+                if self.vae_parallel:    # layer-pipelined decode over all ranks, video assembled on rank 0
+                    out = self.vae.decode_pipelined(x0)
+                    return out if self.rank == 0 else None
+                return self.vae.decode(x0) if self.rank == 0 else None
+            retry = False
+            try:
+                videos = decode()
+            except torch.cuda.OutOfMemoryError:
+                if not offload_model or offloaded or self.vae_parallel:      # (pipelined decode: one rank retrying alone would leave its peers in their send / recv)
+                    raise
+                retry = True       # decided here, done BELOW: inside the handler the live exception's traceback still holds the failed decode's
+                #                    frames — its multi-GB fp32 activations — and neither model.cpu() nor empty_cache() could free them
+            if retry:
+                logging.warning('offload_model: the VAE decode ran out of memory beside the resident DiT -> moving the '
+                                'DiT to the host (reference text2video.py:257-259) and decoding again')
+                gc.collect()
+                self.model.cpu()
+                torch.cuda.empty_cache()
+                offloaded = True
+                videos = decode()
             self.last_offloaded = offloaded
 
         del noise, latent, sample_scheduler
