@@ -230,7 +230,12 @@ __global__ __launch_bounds__(V11_THREADS, 1) void gemm_bf16_v12_kernel(
             const int64_t m_wave = m0 + wm * 128;
             const int n_wave = n0 + wn * 128;
             if (!(flags & 16) && m_wave + 128 <= M && n_wave + 128 <= N)      // the wave's whole 128 x 128 block exists (wave-uniform)
-                v11_epilogue_rows<EPI>(acc, smem + stage_last + wave * 16384, lane, r16, G, m_wave, n_wave, bias, gate, out, ldo);
+            {
+                if (flags & 1)      // measurement: the round-4 form (each residual batch waited for with nothing else in flight)
+                    v11_epilogue_rows<EPI>(acc, smem + stage_last + wave * 16384, lane, r16, G, m_wave, n_wave, bias, gate, out, ldo);
+                else
+                    v11_epilogue_rows2<EPI>(acc, smem + stage_last + wave * 16384, lane, r16, G, m_wave, n_wave, bias, gate, out, ldo);
+            }
             else
                 mg_gemm_epilogue16<EPI, 8, 8>(acc, m_wave, n_wave, r16, G, (flags & 4) ? 0 : M, N, bias, gate, out, ldo);
         }
@@ -281,7 +286,7 @@ int mg_gemm_v2_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_
                       int epilogue, void* out, int64_t ldo, const float* gate, hipStream_t st);      // gemm_bf16_v2.hip
 
 #ifdef MG_AB_BUILD
-static int g_v12_flags = 0;     // measurement bits (mg_gemm_set_variant(200 + flags)): 2 = raster 0 always, 4 = no stores (timing only), 16 = fp32 outputs: direct epilogue, 32 * (1 + s) = generated body s (0 / 2)
+static int g_v12_flags = 0;     // measurement bits (mg_gemm_set_variant(200 + flags)): 1 = fp32 outputs: residual batches not pipelined, 2 = raster 0 always, 4 = no stores (timing only), 16 = fp32 outputs: direct epilogue, 32 * (1 + s) = generated body s (0 / 2)
 void mg_gemm_v12_set_flags(int f) { g_v12_flags = f; }
 #else
 static constexpr int g_v12_flags = 0;

@@ -240,3 +240,100 @@ MG_DEV void v11_epilogue_rows(const f32x4_t (&acc)[8][8], char* __restrict__ sp,
     }
 #undef V11_WAVE_LDS_FENCE
 }
+
+// The same epilogue with the residual loads as a ROLLING WINDOW (round 5; variant 12).  v11_epilogue_rows issues a batch of 16 row-segment loads
+// and waits for it twice per pass with nothing else in flight — and its three 16-deep register arrays (loads, results, LDS read-back: 160 registers
+// beside the kernel's state) spill; every scratch reload is a vmcnt(0), i.e. a full drain of whatever was in flight.  Of a tile's 28.9 us outside the
+// k-loop (profiles/r05e_gemm_v12_tilecost.log) that is about four exposed round trips.  Here the tile's 128 row pairs are 8 groups of 8 instructions;
+// two groups (16 loads, 16 KiB per wave) are always on their way: a group's results are computed IN PLACE in its load registers (8 distinct quads,
+// kept until its 8 stores are issued: the store-data hazard above), then the registers take the loads of the group after next — across the pass
+// boundary too.  80 registers instead of 160, no spill.  Same arithmetic, element for element.
+template <int EPI>
+MG_DEV void v11_epilogue_rows2(const f32x4_t (&acc)[8][8], char* __restrict__ sp, int lane, int r16, int G, int64_t m_wave, int n_wave,
+                               const float* __restrict__ bias, const float* __restrict__ gate, void* __restrict__ out, int64_t ldo) {
+    static_assert(EPI == MG_EPI_GATE_RESID_F32 || EPI == MG_EPI_BIAS_F32, "fp32 outputs only");
+    constexpr bool RES = EPI == MG_EPI_GATE_RESID_F32;
+    const int c8 = lane & 31, half = lane >> 5;
+    float4 g4 = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (RES && gate) g4 = *(const float4*)(gate + n_wave + 4 * c8);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((float*)out + m_wave * ldo + n_wave, 0, 0x7fffffff, 0x00020000);
+    const int row_bytes = (int)ldo * 4;
+    const int voff = half * row_bytes + c8 * 16;
+    const unsigned wr = (unsigned)(uintptr_t)(v11_lptr_t)sp + r16 * 256 + (G & 1) * 8;
+    char* const rd = sp + half * 256 + (c8 & 1) * 8;
+#define V11_FENCE asm volatile("" ::: "memory")      // compiler-level: LDS exchange between the lanes of a wave; and loads stay in front of it
+    // the bias BEFORE the residual stream starts: a load behind it would be waited for with vmcnt counting every older load too
+    f32x4_t b4[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) b4[c] = bias ? *(const f32x4_t*)(bias + n_wave + c * 16 + G * 4) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    asm volatile("" : "+v"(b4[0]), "+v"(b4[1]), "+v"(b4[2]), "+v"(b4[3]), "+v"(b4[4]), "+v"(b4[5]), "+v"(b4[6]), "+v"(b4[7]) :: "memory");
+    v11_u4 x[2][8];
+    // group gid = 0..7: pass gid >> 2, row pairs 8 (gid & 3) .. + 7 of the pass (row pair q = rows 2q, 2q + 1 of the pass's 64 tokens)
+    auto issue = [&](int gid) __attribute__((always_inline)) {
+        if (RES) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                x[gid & 1][u] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, ((gid >> 2) * 64 + ((gid & 3) * 8 + u) * 2) * row_bytes, 0);
+        }
+        V11_FENCE;
+    };
+    auto transpose = [&](int pass) __attribute__((always_inline)) {
+        V11_FENCE;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int chunk = ((2 * c + (G >> 1)) ^ r16) << 4;
+            v11_u2 p[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int j = pass * 4 + jj;
+                p[jj].x = pack_bf2(acc[c][j][0] + b4[c][0], acc[c][j][1] + b4[c][1]);       // the reference's bf16 Linear output
+                p[jj].y = pack_bf2(acc[c][j][2] + b4[c][2], acc[c][j][3] + b4[c][3]);
+            }
+            v11_lds_write2<0>(wr + chunk, p[0], p[1]);
+            v11_lds_write2<8192>(wr + chunk, p[2], p[3]);
+        }
+        V11_FENCE;
+    };
+    auto group = [&](int gid) __attribute__((always_inline)) {
+        v11_u4 (&xg)[8] = x[gid & 1];
+        const int pass = gid >> 2, q0 = (gid & 3) * 8;
+        v11_u2 d[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int row2 = (q0 + u) * 2;                  // this lane's row: row2 + half
+            d[u] = *(const v11_u2*)(rd + row2 * 256 + (((c8 >> 1) ^ ((row2 & 15) | half)) << 4));
+        }
+        if (RES)       // this group's loads are waited for HERE, as one batch; the younger group stays in flight (the compiler counts vmcnt)
+            asm volatile("" : "+v"(xg[0]), "+v"(xg[1]), "+v"(xg[2]), "+v"(xg[3]), "+v"(xg[4]), "+v"(xg[5]), "+v"(xg[6]), "+v"(xg[7]) :: "memory");
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int row2 = (q0 + u) * 2;
+            const float v[4] = {__uint_as_float(d[u].x << 16), __uint_as_float(d[u].x & 0xffff0000u),
+                                __uint_as_float(d[u].y << 16), __uint_as_float(d[u].y & 0xffff0000u)};
+            v11_u4 r = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+            if (RES) {
+                // torch evaluates `x + y * e` as a rounded product and a rounded sum (two kernels): no fma here
+#pragma clang fp contract(off)
+                r.x = __float_as_uint(__uint_as_float(xg[u].x) + v[0] * g4.x);
+                r.y = __float_as_uint(__uint_as_float(xg[u].y) + v[1] * g4.y);
+                r.z = __float_as_uint(__uint_as_float(xg[u].z) + v[2] * g4.z);
+                r.w = __float_as_uint(__uint_as_float(xg[u].w) + v[3] * g4.w);
+            }
+            xg[u] = r;
+            __builtin_amdgcn_raw_buffer_store_b128(xg[u], rs, voff, (pass * 64 + row2) * row_bytes, 0);
+        }
+        // no result register is reused before all 8 stores are out, and nothing overwrites one for two more cycles
+        asm volatile("s_nop 1" ::"v"(xg[0]), "v"(xg[1]), "v"(xg[2]), "v"(xg[3]), "v"(xg[4]), "v"(xg[5]), "v"(xg[6]), "v"(xg[7]) : "memory");
+    };
+    issue(0);
+    issue(1);
+    transpose(0);
+#pragma unroll
+    for (int gid = 0; gid < 8; ++gid) {
+        if (gid == 4) transpose(1);          // every read-back of pass 0 has been issued: a wave's LDS instructions execute in order
+        group(gid);
+        if (gid + 2 < 8) issue(gid + 2);
+    }
+    V11_FENCE;
+#undef V11_FENCE
+}
