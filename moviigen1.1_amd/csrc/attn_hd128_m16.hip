@@ -65,6 +65,7 @@ struct M16State {
     bf16x8_t pf[2][4];     // P   [unit kb][query block]: keys 8G..8G+7 of the unit
     f32x4_t mq[4];         // -m_ref of the lane's query in block n, four copies: C operand of an accumulator's first MFMA
     float m_run[4], l_run[4];
+    float psa[4], psb[4];  // the pipelined pass's row-sum partials (even / odd score of a pair), folded into l_run ONCE behind the pass
     int bad;
 };
 
@@ -164,11 +165,14 @@ MG_DEV void m16_mask_init(M16State& s, int lim, int G, const f32x4_t (&base)[4])
 // of unit 1-KB when SM.  `dma(i)` is called once per group (i = 0..7).  Fragment ring: 4 K + 4 V registers, reads two
 // groups (16 MFMAs) ahead; the reads of the first two groups must have been issued by the caller (prefetch()), the last
 // two groups of this step issue them for the NEXT step from nk / nv (0 = the clamped address of this step: data unused).
-template <int KB, int SMODE, bool PV, bool SM, bool SCALED, int ORD, typename Dma>
+// LKO / LVO / NKO / NVO: constant byte offsets added to lds_k / lds_v / nk / nv in the reads' immediate fields — the steady loop passes the
+// SLOT's base address (a register carried across tiles) and names the unit inside the slot here: no address arithmetic per step.
+template <int KB, int SMODE, bool PV, bool SM, bool SCALED, int ORD, int LKO = 0, int LVO = 0, int NKO = 0, int NVO = 0, typename Dma>
 MG_DEV void m16_step(M16State& s, const bf16x8_t (&qf)[4][4], bf16x8_t (&kf)[4], bf16x8_t (&vf)[4], unsigned lds_k,
                      unsigned lds_v, unsigned nk, unsigned nv, float c, Dma dma) {
     constexpr int SB = 1 - KB;          // unit being exponentiated
-    float psa[4] = {0.f, 0.f, 0.f, 0.f}, psb[4] = {0.f, 0.f, 0.f, 0.f};
+    // (row-sum partials: s.psa / s.psb, carried through the whole pass — summed into l_run at the end of every step they were 9 VALU
+    // instructions, 7 of them packed, at the bottom of each tile with the matrix pipe empty)
     u32x4_t w[4];
     float pa[2] = {0.f, 0.f}, pb[2] = {0.f, 0.f};
     // softmax of pair pp = 2i + half (16 pairs per unit): query block n = pp >> 2, packed word pp & 3 = (key block,
@@ -192,15 +196,15 @@ MG_DEV void m16_step(M16State& s, const bf16x8_t (&qf)[4][4], bf16x8_t (&kf)[4],
     auto add_a = [&](int i, int half) __attribute__((always_inline)) {
         if (SM) {
             const int n = (2 * i + half) >> 2;
-            psa[n] += pa[half];
-            asm volatile("" : "+v"(psa[n]));
+            s.psa[n] += pa[half];
+            asm volatile("" : "+v"(s.psa[n]));
         }
     };
     auto add_b = [&](int i, int half) __attribute__((always_inline)) {
         if (SM) {
             const int n = (2 * i + half) >> 2;
-            psb[n] += pb[half];
-            asm volatile("" : "+v"(psb[n]));
+            s.psb[n] += pb[half];
+            asm volatile("" : "+v"(s.psb[n]));
         }
     };
     auto cvt = [&](int i, int half) __attribute__((always_inline)) {
@@ -228,29 +232,29 @@ MG_DEV void m16_step(M16State& s, const bf16x8_t (&qf)[4][4], bf16x8_t (&kf)[4],
         if (SMODE == 0) asm volatile("" ::"v"(kf[r2]));
         if (i < 6) {
             switch (i) {   // compile-time after unrolling
-                case 0: m16_rd<m16_koff(2)>(kf[r2], lds_k); break;
-                case 1: m16_rd<m16_koff(3)>(kf[r2], lds_k); break;
-                case 2: m16_rd<m16_koff(4)>(kf[r2], lds_k); break;
-                case 3: m16_rd<m16_koff(5)>(kf[r2], lds_k); break;
-                case 4: m16_rd<m16_koff(6)>(kf[r2], lds_k); break;
-                default: m16_rd<m16_koff(7)>(kf[r2], lds_k); break;
+                case 0: m16_rd<m16_koff(2) + LKO>(kf[r2], lds_k); break;
+                case 1: m16_rd<m16_koff(3) + LKO>(kf[r2], lds_k); break;
+                case 2: m16_rd<m16_koff(4) + LKO>(kf[r2], lds_k); break;
+                case 3: m16_rd<m16_koff(5) + LKO>(kf[r2], lds_k); break;
+                case 4: m16_rd<m16_koff(6) + LKO>(kf[r2], lds_k); break;
+                default: m16_rd<m16_koff(7) + LKO>(kf[r2], lds_k); break;
             }
-        } else if (i == 6) m16_rd<m16_koff(0)>(kf[r2], nk);
-        else m16_rd<m16_koff(1)>(kf[r2], nk);
+        } else if (i == 6) m16_rd<m16_koff(0) + NKO>(kf[r2], nk);
+        else m16_rd<m16_koff(1) + NKO>(kf[r2], nk);
     };
     auto rdV = [&](int i) __attribute__((always_inline)) {
         const int r2 = (i + 2) & 3;
         if (i < 6) {
             switch (i) {
-                case 0: m16_rd<m16_voff(2)>(vf[r2], lds_v); break;
-                case 1: m16_rd<m16_voff(3)>(vf[r2], lds_v); break;
-                case 2: m16_rd<m16_voff(4)>(vf[r2], lds_v); break;
-                case 3: m16_rd<m16_voff(5)>(vf[r2], lds_v); break;
-                case 4: m16_rd<m16_voff(6)>(vf[r2], lds_v); break;
-                default: m16_rd<m16_voff(7)>(vf[r2], lds_v); break;
+                case 0: m16_rd<m16_voff(2) + LVO>(vf[r2], lds_v); break;
+                case 1: m16_rd<m16_voff(3) + LVO>(vf[r2], lds_v); break;
+                case 2: m16_rd<m16_voff(4) + LVO>(vf[r2], lds_v); break;
+                case 3: m16_rd<m16_voff(5) + LVO>(vf[r2], lds_v); break;
+                case 4: m16_rd<m16_voff(6) + LVO>(vf[r2], lds_v); break;
+                default: m16_rd<m16_voff(7) + LVO>(vf[r2], lds_v); break;
             }
-        } else if (i == 6) m16_rd<m16_voff(0)>(vf[r2], nv);
-        else m16_rd<m16_voff(1)>(vf[r2], nv);
+        } else if (i == 6) m16_rd<m16_voff(0) + NVO>(vf[r2], nv);
+        else m16_rd<m16_voff(1) + NVO>(vf[r2], nv);
     };
 #define M16_SB() __builtin_amdgcn_sched_barrier(0)
 #pragma unroll
@@ -370,7 +374,6 @@ MG_DEV void m16_step(M16State& s, const bf16x8_t (&qf)[4][4], bf16x8_t (&kf)[4],
     if (SM) {
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
-            s.l_run[n] += psa[n] + psb[n];     // (l only grows, inf / NaN are sticky: ONE range test of the final sum)
             s.pf[SB][n] = m16_bf(w[n]);
         }
     }
@@ -448,7 +451,7 @@ __global__ __launch_bounds__(M16_THREADS, 1) void attn_hd128_m16_kernel(
 #pragma unroll
             for (int n = 0; n < 4; ++n) s.ot[d][n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int n = 0; n < 4; ++n) s.m_run[n] = -1e30f, s.l_run[n] = 0.f;
+        for (int n = 0; n < 4; ++n) s.m_run[n] = -1e30f, s.l_run[n] = 0.f, s.psa[n] = 0.f, s.psb[n] = 0.f;
         s.bad = 0;
     };
     reset();
@@ -586,29 +589,84 @@ __global__ __launch_bounds__(M16_THREADS, 1) void attn_hd128_m16_kernel(
         // step u = 1: S(1,0) | P.V(0,0) | softmax S(0,1)
         prefetch(k_addr(1, 0), v_addr(0, 0));
         m16_step<0, 1, true, true, SCALED, ORD>(s, qf, kf, vf, k_addr(1, 0), v_addr(0, 0), k_addr(1, 1), v_addr(0, 1), c_log2, M16NoDma());
-        int s0 = 0, s1 = 1, s2 = 2;     // slots of tiles t-1, t, t+1
         int t = 1;
         unsigned long long pf_fence = 0, pf_a = 0, pf_b = 0, pf_n = 0;
+        // ---- steady loop, with its state CARRIED instead of recomputed (round 5).  Per tile the loop used to spend ~35 instructions outside
+        // MFMA gaps — slot indices -> eight LDS read addresses, two 64-bit global addresses with their clamps, M0 values — clumped at the top of
+        // the tile and in front of the first K / V piece, each with the matrix pipe empty (one wave per SIMD).  Now:
+        //   * the read addresses of slots (tile t-1, t, t+1) live in three registers per operand and ROTATE by two v_swap_b32 each, in the
+        //     last gap of step B; the unit inside a slot (+512 / +8192 bytes) is in the reads' immediate fields (m16_step LKO ...);
+        //   * the refill loads are BUFFER loads: the head's K / V images behind two resources (num_records = the head's bytes: a tile index past
+        //     the end reads zeros into a slot nobody reads — no clamp), one per-lane offset per piece, the tile's byte offset in a scalar that
+        //     advances by 16 KiB in a gap; the LDS destination = a scalar per slot, rotating with three s_mov in a gap;
+        //   * M0 is saved ONCE in front of the loop and restored ONCE behind it: the compiler tracks M0 for its own (builtin) LDS-DMA loads of the
+        //     prologue and the tail — it hoists and merges identical M0 writes — and must find the register as it left it.  (Saved and restored
+        //     inside every load's statement, the restore stood directly behind the load and waited for it: 110 cycles per piece.)
+        unsigned ka0 = k_addr(0, 0), ka1 = k_addr(1, 0), ka2 = k_addr(2, 0);      // K read bases of the slots of tiles t-1, t, t+1
+        unsigned va0 = v_addr(0, 0), va1 = v_addr(1, 0), va2 = v_addr(2, 0);
+        unsigned lk0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + M16_K(0) + wave * 4096));      // this wave's piece 0 in those slots (K; V: + 3 tiles)
+        unsigned lk1 = lk0 + M16_TILE, lk2 = lk0 + 2 * M16_TILE;
+        int offk = (t + 2) * M16_TILE, offv = (t + 1) * M16_TILE;                 // byte offsets of tiles t+2 (K) / t+1 (V) in the head's image
+        const uint64_t kb64 = (uint64_t)(uintptr_t)(kp + ((int64_t)head * T) * 8192), vb64 = (uint64_t)(uintptr_t)(vp + ((int64_t)head * T) * 8192);
+        const u32x4_t rs_k = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)kb64), (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(kb64 >> 32) & 0xffffu)),
+                              (unsigned)T * M16_TILE, 0x00020000u};
+        const u32x4_t rs_v = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)vb64), (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(vb64 >> 32) & 0xffffu)),
+                              (unsigned)T * M16_TILE, 0x00020000u};
+        const int dvo = wave * 4096 + lane * 16;      // this lane's 16 bytes of piece 0 inside a tile image
+        unsigned keep_m0, rot_tmp;
+#define M16_BDMA0(VOFF, RS, SOFF, LBASE, IMM)                                                                                              \
+    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %4 offen lds"                                             \
+                 :: "v"(VOFF), "s"(RS), "s"(LBASE), "n"(IMM), "s"(SOFF) : "memory", "scc")
+#define M16_BDMAN(VOFF, RS, SOFF, IMM)                                                                                                     \
+    asm volatile("buffer_load_dwordx4 %0, %1, %3 offen offset:%2 lds" :: "v"(VOFF), "s"(RS), "n"(IMM), "s"(SOFF) : "memory")
+        asm volatile("s_mov_b32 %0, m0\n\ts_nop 4" : "=s"(keep_m0) :: "memory");      // the resources were just written by v_readfirstlane; the loads below are opaque to the hazard recognizer
+        // The carried registers may be scratch reloads of the preheader: with no VMEM instruction of its own in the loop (the loads are opaque
+        // asm) the compiler's wait-count pass would carry "reload pending" around the back edge and wait vmcnt(1) in front of a fragment read in
+        // the MIDDLE of step A — i.e. for the refill loads just issued (measured: step A 1275 -> 2150 cycles).  A wait it can see, out here:
+        __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0)
+        asm volatile("" : "+v"(ka0), "+v"(ka1), "+v"(ka2), "+v"(va0), "+v"(va1), "+v"(va2));
         for (; t + 1 < nfull; ++t) {
             const unsigned long long c0 = PROF ? __builtin_amdgcn_s_memtime() : 0;
             fence_hot();                // K(t+1), V(t) visible; everyone is past iteration t-1
             const unsigned long long c1 = PROF ? __builtin_amdgcn_s_memtime() : 0;
-            // u = 2t: S(t,1) [K slot s1] | P.V(t-1,1) [V slot s0] | softmax S(t,0); refill K(t+2) -> slot s0, V(t+1) -> slot s2
-            m16_step<1, 1, true, true, SCALED, ORD>(s, qf, kf, vf, k_addr(s1, 1), v_addr(s0, 1), k_addr(s2, 0), v_addr(s1, 0), c_log2,
-                                       [&](int n) __attribute__((always_inline)) {   // all 8 refill pieces here:
-                                           if (n < 4) dma_k(t + 2, s0, n);            // K(t+2) -> slot of tile t-1,
-                                           else dma_v(t + 1, s2, n - 4);              // V(t+1) -> slot of tile t-2;
-                                       });                                            // step B gives them time to land
+            // u = 2t: S(t,1) [K slot of t] | P.V(t-1,1) [V slot of t-1] | softmax S(t,0); refill K(t+2) -> slot of t-1, V(t+1) -> slot of t+1
+            m16_step<1, 1, true, true, SCALED, ORD, 512, 8192, 0, 0>(s, qf, kf, vf, ka1, va0, ka2, va1, c_log2,
+                                       [&](int n) __attribute__((always_inline)) {   // all 8 refill pieces here (step B gives them time to land)
+                                           switch (n) {
+                                               case 0: M16_BDMA0(dvo, rs_k, offk, lk0, 0); break;       // M0 once per operand: the pieces'
+                                               case 1: M16_BDMAN(dvo, rs_k, offk, 1024); break;         // 1 KiB steps are instruction offsets
+                                               case 2: M16_BDMAN(dvo, rs_k, offk, 2048); break;         // (global and LDS side alike)
+                                               case 3: M16_BDMAN(dvo, rs_k, offk, 3072); break;
+                                               case 4: M16_BDMA0(dvo, rs_v, offv, lk2, 3 * M16_TILE); break;
+                                               case 5: M16_BDMAN(dvo, rs_v, offv, 1024); break;
+                                               case 6: M16_BDMAN(dvo, rs_v, offv, 2048); break;
+                                               default: M16_BDMAN(dvo, rs_v, offv, 3072); break;
+                                           }
+                                       });
             const unsigned long long c2 = PROF ? __builtin_amdgcn_s_memtime() : 0;
-            // u = 2t+1: S(t+1,0) [K slot s2] | P.V(t,0) [V slot s1] | softmax S(t,1)
-            m16_step<0, 1, true, true, SCALED, ORD>(s, qf, kf, vf, k_addr(s2, 0), v_addr(s1, 0), k_addr(s2, 1), v_addr(s1, 1), c_log2, M16NoDma());
+            // u = 2t+1: S(t+1,0) [K slot of t+1] | P.V(t,0) [V slot of t] | softmax S(t,1); in its free gaps the state steps to tile t+1
+            m16_step<0, 1, true, true, SCALED, ORD, 0, 0, 512, 8192>(s, qf, kf, vf, ka2, va1, ka2, va1, c_log2,
+                                       [&](int n) __attribute__((always_inline)) {
+                                           if (n == 0)
+                                               asm volatile("s_add_u32 %0, %0, 0x4000\n\ts_add_u32 %1, %1, 0x4000" : "+s"(offk), "+s"(offv) : : "scc");
+                                           else if (n == 1)      // slots (t-1, t, t+1) -> (t, t+1, t-1)
+                                               asm volatile("s_mov_b32 %3, %0\n\ts_mov_b32 %0, %1\n\ts_mov_b32 %1, %2\n\ts_mov_b32 %2, %3"
+                                                            : "+s"(lk0), "+s"(lk1), "+s"(lk2), "=&s"(rot_tmp));
+                                           else if (n == 7) {    // behind the step's last fragment reads: rotate the read bases the same way, in place
+                                               asm volatile("v_swap_b32 %0, %1\n\tv_swap_b32 %1, %2" : "+v"(ka0), "+v"(ka1), "+v"(ka2));
+                                               asm volatile("v_swap_b32 %0, %1\n\tv_swap_b32 %1, %2" : "+v"(va0), "+v"(va1), "+v"(va2));
+                                           }
+                                       });
             if (PROF) {
                 const unsigned long long c3 = __builtin_amdgcn_s_memtime();
                 pf_fence += c1 - c0, pf_a += c2 - c1, pf_b += c3 - c2, pf_n += 1;
             }
-            const int tmp = s0;
-            s0 = s1, s1 = s2, s2 = tmp;
         }
+#undef M16_BDMA0
+#undef M16_BDMAN
+        asm volatile("s_mov_b32 m0, %0" :: "s"(keep_m0) : "memory");
+        static_assert(M16_TILE == 0x4000, "the literal above");
+        const int s0 = (t - 1) % 3, s1 = t % 3, s2 = (t + 1) % 3;     // slots of tiles t-1, t, t+1 (tile i lives in slot i % 3)
         if (PROF && prof && lane == 0) {
             atomicAdd(prof + wave * 4 + 0, pf_fence);
             atomicAdd(prof + wave * 4 + 1, pf_a);
@@ -645,6 +703,8 @@ __global__ __launch_bounds__(M16_THREADS, 1) void attn_hd128_m16_kernel(
         asm volatile("" ::"v"(kf[0]), "v"(kf[1]), "v"(kf[2]), "v"(kf[3]), "v"(vf[0]), "v"(vf[1]), "v"(vf[2]), "v"(vf[3]));
 #pragma unroll
         for (int n = 0; n < 4; ++n) {       // ONE range test of the final row sums (2^-64 .. 2^90 expected; inf / NaN fail too)
+            s.l_run[n] += s.psa[n] + s.psb[n];      // (l only grows, inf / NaN are sticky)
+            s.psa[n] = s.psb[n] = 0.f;
             float lt = s.l_run[n] + __shfl_xor(s.l_run[n], 16, 64);
             lt += __shfl_xor(lt, 32, 64);
             s.bad |= !(lt >= 8.4703295e-22f && lt <= 1.2379400e27f);       // 2^-70, 2^90

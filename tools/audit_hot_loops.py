@@ -29,7 +29,9 @@ KERNELS = [
     # variant 12: ONE self-looping block — 128 MFMAs + 32 LDS reads + 16 loads + 16 M0 writes + 6 state toggles + 5 counted waits + 3 x
     # (wait + barrier) + ~17 s_nop 0 in front of the M0 writes + the loop's add / compare / branch = 101
     ('gemm_bf16_v12.hip', 'gemm_bf16_v12_kernel', r'kernelILi\dELi\dELb1E', 128, 108),
-    ('attn_hd128_m16.hip', 'attn_hd128_m16_kernel', r'kernelILb1E', 128, 330),
+    # attention: 128 MFMAs + 64 exp + 64 adds + 32 cvt + 32 LDS reads + 8 buffer loads to LDS + waits / state rotation (235; the variant that
+    # scales q in the loop: 299)
+    ('attn_hd128_m16.hip', 'attn_hd128_m16_kernel', r'kernelILb1E', 128, 305),
 ]
 FORBIDDEN = ('scratch_', 'v_cndmask', 'v_readfirstlane')
 MAX_ACC_MOVES = 8      # v_accvgpr_read / _write per iteration (register-file shuffles of a kernel at the 512-register limit)
@@ -92,6 +94,13 @@ def audit(src, frag, skip, n_mfma, max_other):
             problems.append(f'{name}: {other} non-MFMA instructions in the hot block (limit {max_other})')
         if bad:
             problems.append(f'{name}: {bad} in the hot block')
+        # a vmcnt wait the COMPILER put into a loop whose loads are opaque asm = a preheader reload carried around the back edge; it waits for the
+        # loop's own refill loads (attention, round 5: step A 1275 -> 2150 cycles).  The hand-written waits are vmcnt(0) at a fence or counted
+        # waits inside the generated GEMM bodies — those files are exempt.
+        if src.startswith('attn_'):
+            vm = [ln.strip() for ln in best.splitlines() if re.search(r'\bs_waitcnt\b.*vmcnt\((?!0\))', ln)]
+            if vm:
+                problems.append(f'{name}: partial vmcnt wait(s) in the hot block: {vm}')
         acc_moves = sum(1 for i in ins if i.startswith('v_accvgpr_'))
         if acc_moves > MAX_ACC_MOVES:
             problems.append(f'{name}: {acc_moves} v_accvgpr moves in the hot block (limit {MAX_ACC_MOVES})')
