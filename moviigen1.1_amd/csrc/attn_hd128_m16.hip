@@ -37,6 +37,8 @@
 // softmax costs exp + add + half a cvt_pk per score.  SCALED = true (any q, any scale): one v_mul more per score, q is
 // used as given (no second rounding); the reference is kept in raw score units either way.
 #include <type_traits>
+#include <atomic>
+#include <mutex>
 #include "common.h"
 #include "../../include/moviigen_hip.h"
 
@@ -387,25 +389,34 @@ template <bool PROF, bool SCALED, int ORD>
 __global__ __launch_bounds__(M16_THREADS, 1) void attn_hd128_m16_kernel(
     const uint16_t* __restrict__ q, int64_t ldq, const uint16_t* __restrict__ kp, const uint16_t* __restrict__ vp,
     uint16_t* __restrict__ o, int64_t ldo, int64_t Lq, int64_t Lk, int heads, float c_log2, int nqb, int dbg,
-    unsigned long long* __restrict__ prof, float* __restrict__ lse, unsigned* __restrict__ flagcnt) {
+    unsigned long long* __restrict__ prof, float* __restrict__ lse, unsigned* __restrict__ flagcnt, unsigned* __restrict__ tickets) {
     __shared__ __attribute__((aligned(16))) char smem[6 * M16_TILE];
+    __shared__ int s_next_item;
     const int bid = blockIdx.x;
+    const unsigned long long r_start = PROF ? __builtin_amdgcn_s_memrealtime() : 0;     // the 100 MHz counter all workgroups share
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, qi = lane & 15, G = lane >> 4;
-    // persistent, XCD-aware work loop over (head, query block) items, head-major (see attn_hd128_w64.hip)
+    // persistent work loop over (head, query block) items, head-major.  Items are handed out by TICKET (`tickets` != nullptr): the first nwg
+    // items by workgroup index, every further one by an atomic counter, fetched one item ahead.  The static partition this replaces — XCD x owns
+    // items [x, x + 1) * total / 8 — lost 2.0 % of the metric's launch to its tail: the 32 workgroups of an XCD end within 2 us of each other,
+    // but the XCDs do not run at one speed (223.7 ms for the slowest, 211.0 ms for the fastest: profiles/r05v_attn_balance.log).  In ticket
+    // order the XCD's workgroups still take neighbouring query blocks of one head at nearly the same moment and walk its K / V together.
     const int total_items = nqb * heads;
     const int nwg = gridDim.x;
+    const bool ticketed = tickets != nullptr && nwg != total_items;
     int item, item_end, item_step;
-    if (nwg == total_items) {
-        item = bid, item_end = bid + 1, item_step = 1;
-    } else {
+    if (nwg == total_items || ticketed) {
+        item = bid, item_end = ticketed ? total_items : bid + 1, item_step = 1;
+    } else {            // (measurement: the static, XCD-contiguous partition)
         const int xcd = bid & 7, slot = bid >> 3;
         item = (int)((int64_t)xcd * total_items / 8) + slot;
         item_end = (int)((int64_t)(xcd + 1) * total_items / 8);
         item_step = nwg >> 3;           // host guarantees nwg % 8 == 0 here
     }
-    for (; item < item_end; item += item_step) {
+    unsigned next_ticket = 0;
+    while (item < item_end) {
+    if (ticketed && tid == 0) next_ticket = atomicAdd(tickets, 1u);      // the item after this one; the answer has 2.8 ms to arrive
     const int head = item / nqb;
     const int qb0 = item - head * nqb;
     __syncthreads();                    // the previous item's last LDS reads are done before this one's DMA
@@ -757,7 +768,41 @@ __global__ __launch_bounds__(M16_THREADS, 1) void attn_hd128_m16_kernel(
             }
         }
     }
+    if (ticketed) {
+        if (tid == 0) s_next_item = nwg + (int)next_ticket;
+        __syncthreads();
+        item = __builtin_amdgcn_readfirstlane(s_next_item);
+    } else
+        item += item_step;
     }   // work loop
+    // the last workgroup to leave re-arms the pair {next ticket, workgroups done} for the launch that uses this slot of the ring next
+    if (ticketed && tid == 0 && atomicAdd(tickets + 1, 1u) == (unsigned)nwg - 1) {
+        __hip_atomic_store(tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(tickets + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (PROF && prof && tid == 0) prof[16 + 2 * bid] = r_start, prof[16 + 2 * bid + 1] = __builtin_amdgcn_s_memrealtime();      // the last launch's {start, end} per workgroup
+}
+
+// Ticket counters of the persistent launches: a ring of {next ticket, workgroups done} pairs per device, zero when idle (a launch leaves its
+// pair zeroed).  Every launch takes the next pair: launches in flight on different streams never share one (the ring is far longer than any
+// queue of attention launches), and a captured launch that is replayed finds its pair re-armed by its previous run.
+#define M16_TICKET_SLOTS 4096
+static unsigned* g_m16_ticket_ring[16] = {};
+static std::atomic<unsigned> g_m16_ticket_next{0};
+static std::mutex g_m16_ticket_mutex;
+static unsigned* m16_ticket_pair() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    if (!g_m16_ticket_ring[dev]) {
+        std::lock_guard<std::mutex> lock(g_m16_ticket_mutex);
+        if (!g_m16_ticket_ring[dev]) {
+            unsigned* p = nullptr;
+            if (hipMalloc(&p, M16_TICKET_SLOTS * 2 * sizeof(unsigned)) != hipSuccess) return nullptr;
+            if (hipMemset(p, 0, M16_TICKET_SLOTS * 2 * sizeof(unsigned)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return nullptr;
+            g_m16_ticket_ring[dev] = p;
+        }
+    }
+    return g_m16_ticket_ring[dev] + 2 * (g_m16_ticket_next.fetch_add(1) % M16_TICKET_SLOTS);
 }
 
 static int g_m16_dbg = 0;
@@ -781,10 +826,17 @@ int mg_attn_m16_launch(const uint16_t* q, int64_t ldq, const uint16_t* kp, const
     if (n_cu < 8) n_cu = 8;
     const int total = nqb * heads;
     const unsigned grid = total <= n_cu ? (unsigned)total : (unsigned)n_cu;   // persistent when there is more work than CUs
+    // Items by ticket from 32 rounds on (the metric's launch has 80: +1.35 %, 220.3 against 223.3 ms; 16 rounds: -0.2 %, and at the 10 rounds of
+    // a sequence-parallel rank nobody has a spare item to take — profiles/r05w_attn_tickets.log); below that the static per-XCD partition.
+    unsigned* tickets = nullptr;
+    if ((int64_t)total >= 32 * (int64_t)grid && !(g_m16_dbg & 16)) {      // (debug bit 4, A/B library: the static partition always)
+        tickets = m16_ticket_pair();
+        if (!tickets) return MG_ERR_LAUNCH;
+    }
 #define M16_ORD 1      // the filler placement the library ships (m16_step): one v_exp_f32 per MFMA gap, alone (profiles/r05m_attn_order.log: +4.8 % over placement 0)
 #define M16_LAUNCH(PROF, SCALED, ORD)                                                                                             \
     hipLaunchKernelGGL((attn_hd128_m16_kernel<PROF, SCALED, ORD>), dim3(grid), dim3(M16_THREADS), 0, st, q, ldq, kp, vp, o, ldo, Lq, \
-                       Lk, heads, prescaled ? 1.0f : c_log2, nqb, g_m16_dbg, PROF ? g_m16_prof : nullptr, lse, g_m16_flagcnt)
+                       Lk, heads, prescaled ? 1.0f : c_log2, nqb, g_m16_dbg, PROF ? g_m16_prof : nullptr, lse, g_m16_flagcnt, tickets)
 #ifdef MG_AB_BUILD
     const int ord = (g_m16_dbg >> 1) & 7;     // measurement: mg_attn_w64_debug(2 * k) runs the pre-scaled entry on placement k
     if (ord && prescaled && !g_m16_prof) {

@@ -34,6 +34,7 @@ __global__ __launch_bounds__(V11_THREADS, 1) void gemm_bf16_v12_kernel(
     unsigned long long pt[5] = {0, 0, 0, 0, 0}, ta = 0;                    // PROF: s_memtime {wait at the lgkmcnt barriers, -, wait at the vmcnt barrier, whole body, bodies}
     unsigned long long pe[3] = {0, 0, 0};                                  // PROF: {whole kernel, last body's close + epilogue + tile prologue, tiles}
     const unsigned long long t_start = PROF ? __builtin_amdgcn_s_memtime() : 0;
+    const unsigned long long r_start = PROF ? __builtin_amdgcn_s_memrealtime() : 0;      // the 100 MHz counter all workgroups share: [64 + 2 bid] = {start, end} of the LAST launch
 
     constexpr bool PAIRED = EPI == MG_EPI_BIAS_BF16 || EPI == MG_EPI_BIAS_GELU_BF16;
     const int nwg = gridDim.x, bid = blockIdx.x;
@@ -279,6 +280,7 @@ __global__ __launch_bounds__(V11_THREADS, 1) void gemm_bf16_v12_kernel(
         pe[0] = __builtin_amdgcn_s_memtime() - t_start;
 #pragma unroll
         for (int i = 0; i < 3; ++i) atomicAdd(prof + 32 + wave * 3 + i, pe[i]);
+        if (wave == 0) prof[64 + 2 * bid] = r_start, prof[64 + 2 * bid + 1] = __builtin_amdgcn_s_memrealtime();
     }
 }
 

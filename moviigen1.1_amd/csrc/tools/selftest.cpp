@@ -663,18 +663,38 @@ int main(int argc, char** argv) {
     }
     if (argc > 1 && !strcmp(argv[1], "w64prof")) {  // s_memtime breakdown of the w64 hot loop
         unsigned long long* buf;
-        CK(hipMalloc(&buf, 16 * 8));
-        CK(hipMemset(buf, 0, 16 * 8));
+        CK(hipMalloc(&buf, (16 + 1024) * 8));
+        CK(hipMemset(buf, 0, (16 + 1024) * 8));
         mg_attn_set_variant(argc > 4 ? atoi(argv[4]) : 0);
         mg_attn_w64_profile(buf);                // (both kernels share the hook)
         if (argc > 6) mg_attn_w64_debug(atoi(argv[6]));
-        test_attn(75600, argc > 2 ? atoll(argv[2]) : 75584, argc > 3 ? atoi(argv[3]) : 8, 8, true, argc > 5 ? atoi(argv[5]) : 1);
+        test_attn(argc > 7 ? atoll(argv[7]) : 75600, argc > 2 ? atoll(argv[2]) : 75584, argc > 3 ? atoi(argv[3]) : 8, 8, true, argc > 5 ? atoi(argv[5]) : 1);
         unsigned long long h[16];
         CK(hipMemcpy(h, buf, sizeof h, hipMemcpyDeviceToHost));
         for (int w = 0; w < 4; ++w) {
             const double n = (double)h[w * 4 + 3];
             printf("wave %d: iterations %.0f  fence %.0f  step A %.0f  step B %.0f  (cycles per tile, 64 MFMAs)\n", w, n, h[w * 4] / n,
                    h[w * 4 + 1] / n, h[w * 4 + 2] / n);
+        }
+        {   // the last launch's {start, end} of every workgroup on the shared 100 MHz counter: what the static item partition loses to its tail
+            std::vector<unsigned long long> se(1024);
+            CK(hipMemcpy(se.data(), buf + 16, 1024 * 8, hipMemcpyDeviceToHost));
+            unsigned long long t0 = ~0ull, t1 = 0;
+            int nw = 0;
+            for (int b = 0; b < 512 && se[2 * b + 1]; ++b) t0 = std::min(t0, se[2 * b]), t1 = std::max(t1, se[2 * b + 1]), ++nw;
+            if (nw) {
+                double mean_end = 0, xe[8] = {0}, xmax[8] = {0}, xmin[8];
+                int xn[8] = {0};
+                for (int x = 0; x < 8; ++x) xmin[x] = 1e30;
+                for (int b = 0; b < nw; ++b) {
+                    const double e = (double)(se[2 * b + 1] - t0) / 100.0;      // microseconds
+                    mean_end += e, xe[b & 7] += e, xn[b & 7]++, xmax[b & 7] = std::max(xmax[b & 7], e), xmin[b & 7] = std::min(xmin[b & 7], e);
+                }
+                printf("workgroups %d: first start -> last end %.1f us; mean end %.1f us (a balanced kernel would end there: %.2f %% lost to the tail)\n", nw,
+                       (double)(t1 - t0) / 100.0, mean_end / nw, 100.0 * (1.0 - mean_end / nw / ((double)(t1 - t0) / 100.0)));
+                for (int x = 0; x < 8; ++x)
+                    if (xn[x]) printf("  XCD %d: first end %.1f  mean end %.1f  last end %.1f us\n", x, xmin[x], xe[x] / xn[x], xmax[x]);
+            }
         }
         mg_attn_w64_profile(nullptr);
         return 0;
@@ -803,8 +823,8 @@ int main(int argc, char** argv) {
     }
     if (argc > 1 && !strcmp(argv[1], "gemmprof")) {  // s_memtime breakdown of the 256x128 GEMM k-loop
         unsigned long long* buf;
-        CK(hipMalloc(&buf, 64 * 8));
-        CK(hipMemset(buf, 0, 64 * 8));
+        CK(hipMalloc(&buf, (64 + 1024) * 8));
+        CK(hipMemset(buf, 0, (64 + 1024) * 8));
         const int gv = argc > 2 ? atoi(argv[2]) : 7;
         mg_gemm_set_variant(gv);
         if (gv >= 7) mg_gemm5_debug_profile(buf); else mg_gemm_debug_profile(buf);
@@ -819,6 +839,24 @@ int main(int argc, char** argv) {
                 const double tiles = (double)h[32 + w * 3 + 2], tot = (double)h[32 + w * 3], epi = (double)h[32 + w * 3 + 1];
                 printf("        per tile: %.0f cycles = bodies %.0f + last k-tile / epilogue / tile prologue %.0f + rest %.0f   (%.0f tiles)\n", tot / tiles,
                        (double)h[w * 5 + 3] / tiles, epi / tiles, (tot - (double)h[w * 5 + 3] - epi) / tiles, tiles);
+            }
+            // the last launch's {start, end} of every workgroup on the shared 100 MHz counter: is the static tile assignment balanced?
+            std::vector<unsigned long long> se(1024);
+            CK(hipMemcpy(se.data(), buf + 64, 1024 * 8, hipMemcpyDeviceToHost));
+            unsigned long long t0 = ~0ull, t1 = 0;
+            int nw = 0;
+            for (int b = 0; b < 512 && se[2 * b + 1]; ++b) t0 = std::min(t0, se[2 * b]), t1 = std::max(t1, se[2 * b + 1]), ++nw;
+            if (nw) {
+                double mean_end = 0, xe[8] = {0}, xs[8] = {0}, xmax[8] = {0};
+                int xn[8] = {0};
+                for (int b = 0; b < nw; ++b) {
+                    const double e = (double)(se[2 * b + 1] - t0) / 100.0, st = (double)(se[2 * b] - t0) / 100.0;      // microseconds
+                    mean_end += e, xe[b & 7] += e, xs[b & 7] += st, xn[b & 7]++, xmax[b & 7] = std::max(xmax[b & 7], e);
+                }
+                printf("workgroups %d: first start -> last end %.1f us; mean end %.1f us (a balanced kernel would end there: %.1f %% lost to the tail)\n", nw,
+                       (double)(t1 - t0) / 100.0, mean_end / nw, 100.0 * (1.0 - mean_end / nw / ((double)(t1 - t0) / 100.0)));
+                for (int x = 0; x < 8; ++x)
+                    if (xn[x]) printf("  XCD %d: mean start %.1f  mean end %.1f  last end %.1f us\n", x, xs[x] / xn[x], xe[x] / xn[x], xmax[x]);
             }
         } else if (gv == 11 || gv >= 110) {      // variant 11: 4 waves x {barrier, to the first MFMA, k-step 0, k-step 1, k-tiles}
             for (int w = 0; w < 4; ++w) {

@@ -321,6 +321,46 @@ def test_attention_reserved_cus_same_bits(dev):
         ops.attention_hd128(q, kp, vp, outs[0], L, N, 1.0, prescaled=True, reserve_cus=-1)
 
 
+def test_attention_items_by_ticket(dev):
+    """the persistent attention grid hands out its (head, query block) items by ticket from 32 rounds on (csrc/attn_hd128_m16.hip: the static
+    per-XCD partition lost 2 % of the metric's launch to the slowest XCD).  Which workgroup computes an item must not show in the result: the same
+    bits as the static partition (A/B library, debug bit 4); the {next ticket, workgroups done} pair a launch used is re-armed by its last
+    workgroup — launch after launch on one stream, two launches in flight on two streams, a smaller grid (reserve_cus) — always the same bits."""
+    from wan.backend import lib, ops
+    L, N = 8192, 260                                       # 32 query blocks x 260 heads = 8320 items = 32.5 rounds of 256 workgroups
+    gen = torch.Generator(device=dev).manual_seed(11)
+    q = (torch.randn(L, N * 128, device=dev, generator=gen) * 0.3).bfloat16()
+    k = torch.randn(L, N * 128, device=dev, generator=gen).bfloat16()
+    v = torch.randn(L, N * 128, device=dev, generator=gen).bfloat16()
+    n_pk = ops.packed_kv_numel(L, N)
+    kp, vp = torch.empty(n_pk, dtype=torch.bfloat16, device=dev), torch.empty(n_pk, dtype=torch.bfloat16, device=dev)
+    ops.pack_kv(k, v, N, kp, vp)
+
+    def run(**kw):
+        o = torch.zeros(L, N * 128, dtype=torch.bfloat16, device=dev)
+        ops.attention_hd128(q, kp, vp, o, L, N, 1.0, prescaled=True, **kw)
+        return o
+    with lib.ab_library() as h:
+        h.mg_attn_w64_debug(16)
+        static = run()
+        torch.cuda.synchronize()
+    assert torch.isfinite(static.float()).all().item() and static.float().abs().max().item() > 0
+    _attn_rows_check(q, k, v, static, [0, 255, 256, L - 1], [0, N - 1], math.log(2.0))      # pre-scaled entry: p = 2^(q.k)
+    for _ in range(3):
+        assert torch.equal(run(), static)
+    assert torch.equal(run(reserve_cus=8), static)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    outs = []
+    for _ in range(2):                                     # two rounds: the second finds the pairs the first round's launches left behind
+        for st in streams:
+            with torch.cuda.stream(st):
+                outs.append(run())
+    torch.cuda.synchronize()
+    for o in outs:
+        assert torch.equal(o, static)
+
+
 @pytest.fixture(params=[0, 3], ids=['m16', 'w64'])
 def attn_variant(request):
     """run a test on the product library's head-dim-128 kernel (m16) and, inside an A/B-library scope, on its measurement partner (w64)."""
