@@ -32,6 +32,7 @@ __global__ __launch_bounds__(V11_THREADS, 1) void gemm_bf16_v12_kernel(
     const float* __restrict__ gate, int tiles_m, int tiles_n, int raster, int flags, unsigned long long* __restrict__ prof) {
     __shared__ __attribute__((aligned(16))) char smem[2 * V11_STAGE];
     unsigned long long pt[5] = {0, 0, 0, 0, 0}, ta = 0;                    // PROF: s_memtime {wait at the lgkmcnt barriers, -, wait at the vmcnt barrier, whole body, bodies}
+    unsigned long long ps[4] = {0, 0, 0, 0}, tsg = 0;                      // PROF: {last k-tile, vmcnt(0) + barrier, epilogue, tile prologue} at [44 + 4 wave]
     unsigned long long pe[3] = {0, 0, 0};                                  // PROF: {whole kernel, last body's close + epilogue + tile prologue, tiles}
     const unsigned long long t_start = PROF ? __builtin_amdgcn_s_memtime() : 0;
     const unsigned long long r_start = PROF ? __builtin_amdgcn_s_memrealtime() : 0;      // the 100 MHz counter all workgroups share: [64 + 2 bid] = {start, end} of the LAST launch
@@ -218,12 +219,36 @@ __global__ __launch_bounds__(V11_THREADS, 1) void gemm_bf16_v12_kernel(
         const unsigned long long te = PROF ? __builtin_amdgcn_s_memtime() : 0;
         // the tile's last k-tile: MFMAs and the k-step-1 fragment reads only
         const unsigned stage_last = lload - lds_pieces;
+        // Measured and not adopted (A/B library, flags & 8): TOUCH the 512 cache lines of `out` the wave's gated-residual epilogue will read (8 loads
+        // of one dword per lane, each lane another 128-byte line) in front of the last k-tile.  The address processing of 64 lines per instruction
+        // holds the wave's issue — last k-tile 4580 -> 16146 cycles — and the epilogue only drops from 39.1 to 35.6 thousand cycles: it does not
+        // wait for HBM (profiles/r05y_gemm_touch.log: 5.70 against 5.50 ms).
+        unsigned touch[8] = {};
+#ifdef MG_AB_BUILD
+        if constexpr (EPI == MG_EPI_GATE_RESID_F32) {
+            if ((flags & 8) && m0 + wm * 128 + 128 <= M && n0 + wn * 128 + 128 <= N) {          // wave-uniform
+                const u32x4_t rs_o = v11_rsrc((const float*)out + (m0 + wm * 128) * ldo + n0 + wn * 128);
+                const int row_bytes = (int)ldo * 4;
+                const int tvoff = (lane >> 2) * row_bytes + (lane & 3) * 128;
+                asm volatile("s_nop 4" ::: "memory");          // the resource was just written by v_readfirstlane; the loads are opaque to the hazard recognizer
+                // (per-load offsets in the VECTOR operand: a scalar offset may come out of a v_readlane spill slot, 5 wait states the assembler
+                // statement would not get — tools/audit_hot_loops.py)
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(touch[i]) : "v"(tvoff + i * 16 * row_bytes), "s"(rs_o) : "memory");
+            }
+        }
+#endif
         V12_SB;
 #include "gemm_bf16_v12_last.inc"
+        if (PROF) { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); tsg = __builtin_amdgcn_s_memtime(); ps[0] += tsg - te; }
         // (builtin MFMAs: the compiler orders the epilogue's accumulator reads behind them.)  Every load has landed — the next tile's
         // k-tile 0 among them — and everyone is done reading this stage, the fp32 epilogues' transposition buffer.
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        // (the touch loads' destination registers stay allocated until here)
+        asm volatile("" :: "v"(touch[0]), "v"(touch[1]), "v"(touch[2]), "v"(touch[3]), "v"(touch[4]), "v"(touch[5]), "v"(touch[6]), "v"(touch[7]));
         V12_SB;
+        if (PROF) { const unsigned long long tt = __builtin_amdgcn_s_memtime(); ps[1] += tt - tsg; tsg = tt; }
         // ---- epilogue (gemm_v11_common.h) ----
         if constexpr (PAIRED)
             v11_epilogue_pair<EPI>(acc, m0 + wm * 128, n0 + wn * 128, r16, G, (flags & 4) ? 0 : M, N, bias, out, ldo);      // flags & 4: measurement without the stores
@@ -234,12 +259,27 @@ __global__ __launch_bounds__(V11_THREADS, 1) void gemm_bf16_v12_kernel(
             {
                 if (flags & 1)      // measurement: the round-4 form (each residual batch waited for with nothing else in flight)
                     v11_epilogue_rows<EPI>(acc, smem + stage_last + wave * 16384, lane, r16, G, m_wave, n_wave, bias, gate, out, ldo);
+#ifdef MG_AB_BUILD
+                else if ((flags & 4) && (flags & 128))      // measurement: neither residual loads nor stores / no stores / no residual loads
+                    v11_epilogue_rows2<EPI, 3>(acc, smem + stage_last + wave * 16384, lane, r16, G, m_wave, n_wave, bias, gate, out, ldo);
+                else if (flags & 4)
+                    v11_epilogue_rows2<EPI, 2>(acc, smem + stage_last + wave * 16384, lane, r16, G, m_wave, n_wave, bias, gate, out, ldo);
+                else if (flags & 128)
+                    v11_epilogue_rows2<EPI, 1>(acc, smem + stage_last + wave * 16384, lane, r16, G, m_wave, n_wave, bias, gate, out, ldo);
+                else if ((flags & 256) && (flags & 512))      // no nt hint on the stores and the residual loads / the stores / the loads
+                    v11_epilogue_rows2<EPI, 12>(acc, smem + stage_last + wave * 16384, lane, r16, G, m_wave, n_wave, bias, gate, out, ldo);
+                else if (flags & 256)
+                    v11_epilogue_rows2<EPI, 4>(acc, smem + stage_last + wave * 16384, lane, r16, G, m_wave, n_wave, bias, gate, out, ldo);
+                else if (flags & 512)
+                    v11_epilogue_rows2<EPI, 8>(acc, smem + stage_last + wave * 16384, lane, r16, G, m_wave, n_wave, bias, gate, out, ldo);
+#endif
                 else
                     v11_epilogue_rows2<EPI>(acc, smem + stage_last + wave * 16384, lane, r16, G, m_wave, n_wave, bias, gate, out, ldo);
             }
             else
                 mg_gemm_epilogue16<EPI, 8, 8>(acc, m_wave, n_wave, r16, G, (flags & 4) ? 0 : M, N, bias, gate, out, ldo);
         }
+        if (PROF) { const unsigned long long tt = __builtin_amdgcn_s_memtime(); ps[2] += tt - tsg; tsg = tt; }
         if (!has_next) {
             if (PROF) pe[1] += __builtin_amdgcn_s_memtime() - te, pe[2] += 1;
             break;
@@ -257,7 +297,7 @@ __global__ __launch_bounds__(V11_THREADS, 1) void gemm_bf16_v12_kernel(
         V12_SB;
         V12_X_ab1; V12_X_wb1; V12_X_abn; V12_X_wbn; V12_X_lload;
         kb = 2 * (V11_BK * 2);
-        if (PROF) pe[1] += __builtin_amdgcn_s_memtime() - te, pe[2] += 1;
+        if (PROF) pe[1] += __builtin_amdgcn_s_memtime() - te, pe[2] += 1, ps[3] += __builtin_amdgcn_s_memtime() - tsg;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no LDS-DMA load may still be on its way when the workgroup's LDS is released
 #undef V12_G
@@ -280,6 +320,8 @@ __global__ __launch_bounds__(V11_THREADS, 1) void gemm_bf16_v12_kernel(
         pe[0] = __builtin_amdgcn_s_memtime() - t_start;
 #pragma unroll
         for (int i = 0; i < 3; ++i) atomicAdd(prof + 32 + wave * 3 + i, pe[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) atomicAdd(prof + 44 + wave * 4 + i, ps[i]);
         if (wave == 0) prof[64 + 2 * bid] = r_start, prof[64 + 2 * bid + 1] = __builtin_amdgcn_s_memrealtime();
     }
 }
@@ -288,7 +330,7 @@ int mg_gemm_v2_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_
                       int epilogue, void* out, int64_t ldo, const float* gate, hipStream_t st);      // gemm_bf16_v2.hip
 
 #ifdef MG_AB_BUILD
-static int g_v12_flags = 0;     // measurement bits (mg_gemm_set_variant(200 + flags)): 1 = fp32 outputs: residual batches not pipelined, 2 = raster 0 always, 4 = no stores (timing only), 16 = fp32 outputs: direct epilogue, 32 * (1 + s) = generated body s (0 / 2)
+static int g_v12_flags = 0;     // measurement bits (mg_gemm_set_variant(200 + flags)): 1 = fp32 outputs: residual batches not pipelined, 2 = raster 0 always, 4 = no stores (timing only), 8 = touch loads in front of the gated-residual epilogue, 128 = fp32 outputs: no residual loads (timing only), 256 / 512 = fp32 outputs: no nt hint on the stores / the residual loads, 16 = fp32 outputs: direct epilogue, 32 * (1 + s) = generated body s (0 / 2)
 void mg_gemm_v12_set_flags(int f) { g_v12_flags = f; }
 #else
 static constexpr int g_v12_flags = 0;
@@ -316,7 +358,7 @@ int mg_gemm_v12_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64
     const dim3 grid((unsigned)nwg), block(V11_THREADS);
     // which generated body: measurement override in bits 5-7 of the flags (mg_gemm_set_variant(200 + 32 * (1 + s))), else body 0 (the six
     // bodies tried differ by < 1 %, profiles/r05c / r05g / r05h_gemm_v12_sched.log)
-    const int sched = (g_v12_flags >> 5) == 3 ? 2 : 0;
+    const int sched = ((g_v12_flags >> 5) & 3) == 3 ? 2 : 0;
 #ifdef MG_AB_BUILD
 #define V12_PROF_BUF(P) ((P) ? g_gemm5_prof : nullptr)
 #else
@@ -324,11 +366,12 @@ int mg_gemm_v12_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64
 #endif
 #define LAUNCH_S(E, S, P)                                                                                                                \
     hipLaunchKernelGGL((gemm_bf16_v12_kernel<E, S, P>), grid, block, 0, st, A, lda, Wt, ldw, bias, M, N, K, out, ldo, gate, tiles_m, tiles_n, \
-                       raster, g_v12_flags & 31, V12_PROF_BUF(P))
+                       raster, g_v12_flags & ~0x60, V12_PROF_BUF(P))
 #ifdef MG_AB_BUILD
 #define LAUNCH(E) do { if (sched == 2) LAUNCH_S(E, 2, false); else LAUNCH_S(E, 0, false); } while (0)
-    if (g_gemm5_prof && epilogue == MG_EPI_BIAS_BF16) {
-        LAUNCH_S(MG_EPI_BIAS_BF16, 0, true);
+    if (g_gemm5_prof && (epilogue == MG_EPI_BIAS_BF16 || epilogue == MG_EPI_GATE_RESID_F32)) {
+        if (epilogue == MG_EPI_BIAS_BF16) LAUNCH_S(MG_EPI_BIAS_BF16, 0, true);
+        else LAUNCH_S(MG_EPI_GATE_RESID_F32, 0, true);
         return mg_check_launch();
     }
 #else

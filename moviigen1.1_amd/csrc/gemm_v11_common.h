@@ -248,11 +248,15 @@ MG_DEV void v11_epilogue_rows(const f32x4_t (&acc)[8][8], char* __restrict__ sp,
 // two groups (16 loads, 16 KiB per wave) are always on their way: a group's results are computed IN PLACE in its load registers (8 distinct quads,
 // kept until its 8 stores are issued: the store-data hazard above), then the registers take the loads of the group after next — across the pass
 // boundary too.  80 registers instead of 160, no spill.  Same arithmetic, element for element.
-template <int EPI>
+// DBG (measurement builds only): 1 = no residual loads (x = 0; wrong results), 2 = no stores (wrong results), 4 = stores without the nt hint, 8 = residual
+// loads without it.  (The tile of `out` is read once and written once: both carry the non-temporal hint — +0.5 % at K = 5120, +1.1 % at K = 13824,
+// profiles/r05y3_gemm_epilogue_parts.log.)
+template <int EPI, int DBG = 0>
 MG_DEV void v11_epilogue_rows2(const f32x4_t (&acc)[8][8], char* __restrict__ sp, int lane, int r16, int G, int64_t m_wave, int n_wave,
                                const float* __restrict__ bias, const float* __restrict__ gate, void* __restrict__ out, int64_t ldo) {
     static_assert(EPI == MG_EPI_GATE_RESID_F32 || EPI == MG_EPI_BIAS_F32, "fp32 outputs only");
     constexpr bool RES = EPI == MG_EPI_GATE_RESID_F32;
+    constexpr bool LOADS = RES && !(DBG & 1), STORES = !(DBG & 2);
     const int c8 = lane & 31, half = lane >> 5;
     float4 g4 = make_float4(1.f, 1.f, 1.f, 1.f);
     if (RES && gate) g4 = *(const float4*)(gate + n_wave + 4 * c8);
@@ -270,10 +274,10 @@ MG_DEV void v11_epilogue_rows2(const f32x4_t (&acc)[8][8], char* __restrict__ sp
     v11_u4 x[2][8];
     // group gid = 0..7: pass gid >> 2, row pairs 8 (gid & 3) .. + 7 of the pass (row pair q = rows 2q, 2q + 1 of the pass's 64 tokens)
     auto issue = [&](int gid) __attribute__((always_inline)) {
-        if (RES) {
+        if (LOADS) {
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                x[gid & 1][u] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, ((gid >> 2) * 64 + ((gid & 3) * 8 + u) * 2) * row_bytes, 0);
+                x[gid & 1][u] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, ((gid >> 2) * 64 + ((gid & 3) * 8 + u) * 2) * row_bytes, (DBG & 8) ? 0 : 2);
         }
         V11_FENCE;
     };
@@ -303,7 +307,11 @@ MG_DEV void v11_epilogue_rows2(const f32x4_t (&acc)[8][8], char* __restrict__ sp
             const int row2 = (q0 + u) * 2;                  // this lane's row: row2 + half
             d[u] = *(const v11_u2*)(rd + row2 * 256 + (((c8 >> 1) ^ ((row2 & 15) | half)) << 4));
         }
-        if (RES)       // this group's loads are waited for HERE, as one batch; the younger group stays in flight (the compiler counts vmcnt)
+        if (!LOADS && RES) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xg[u] = (v11_u4){0u, 0u, 0u, 0u};
+        }
+        if (LOADS)     // this group's loads are waited for HERE, as one batch; the younger group stays in flight (the compiler counts vmcnt)
             asm volatile("" : "+v"(xg[0]), "+v"(xg[1]), "+v"(xg[2]), "+v"(xg[3]), "+v"(xg[4]), "+v"(xg[5]), "+v"(xg[6]), "+v"(xg[7]) :: "memory");
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -320,7 +328,7 @@ MG_DEV void v11_epilogue_rows2(const f32x4_t (&acc)[8][8], char* __restrict__ sp
                 r.w = __float_as_uint(__uint_as_float(xg[u].w) + v[3] * g4.w);
             }
             xg[u] = r;
-            __builtin_amdgcn_raw_buffer_store_b128(xg[u], rs, voff, (pass * 64 + row2) * row_bytes, 0);
+            if (STORES) __builtin_amdgcn_raw_buffer_store_b128(xg[u], rs, voff, (pass * 64 + row2) * row_bytes, (DBG & 4) ? 0 : 2);
         }
         // no result register is reused before all 8 stores are out, and nothing overwrites one for two more cycles
         asm volatile("s_nop 1" ::"v"(xg[0]), "v"(xg[1]), "v"(xg[2]), "v"(xg[3]), "v"(xg[4]), "v"(xg[5]), "v"(xg[6]), "v"(xg[7]) : "memory");

@@ -828,7 +828,7 @@ int main(int argc, char** argv) {
         const int gv = argc > 2 ? atoi(argv[2]) : 7;
         mg_gemm_set_variant(gv);
         if (gv >= 7) mg_gemm5_debug_profile(buf); else mg_gemm_debug_profile(buf);
-        test_gemm(argc > 3 ? atoll(argv[3]) : 75600, argc > 4 ? atoi(argv[4]) : 5120, argc > 5 ? atoi(argv[5]) : 5120, 0, 64, true);
+        test_gemm(argc > 3 ? atoll(argv[3]) : 75600, argc > 4 ? atoi(argv[4]) : 5120, argc > 5 ? atoi(argv[5]) : 5120, argc > 6 ? atoi(argv[6]) : 0, 64, true);
         unsigned long long h[64];
         CK(hipMemcpy(h, buf, sizeof h, hipMemcpyDeviceToHost));
         if (gv == 12 || gv >= 200) {      // variant 12: 4 waves x {BAR1 wait, BAR2 wait, BAR3 wait, whole body, bodies}; the last k-tile of a tile is not a body
@@ -839,6 +839,8 @@ int main(int argc, char** argv) {
                 const double tiles = (double)h[32 + w * 3 + 2], tot = (double)h[32 + w * 3], epi = (double)h[32 + w * 3 + 1];
                 printf("        per tile: %.0f cycles = bodies %.0f + last k-tile / epilogue / tile prologue %.0f + rest %.0f   (%.0f tiles)\n", tot / tiles,
                        (double)h[w * 5 + 3] / tiles, epi / tiles, (tot - (double)h[w * 5 + 3] - epi) / tiles, tiles);
+                printf("        of it: last k-tile %.0f  vmcnt(0) + barrier %.0f  epilogue %.0f  tile prologue %.0f\n", h[44 + w * 4] / tiles, h[44 + w * 4 + 1] / tiles,
+                       h[44 + w * 4 + 2] / tiles, h[44 + w * 4 + 3] / tiles);
             }
             // the last launch's {start, end} of every workgroup on the shared 100 MHz counter: is the static tile assignment balanced?
             std::vector<unsigned long long> se(1024);
