@@ -3,9 +3,10 @@ called from scripts/inference/generate.py:300-313).
 
 The arithmetic (clamp, make_grid normalisation of ONE video, x255, truncating cast to uint8 frames
 [T,H,W,3]) runs on the GPU (mg_video_to_u8, bit-exact with the reference expression).  The container
-encode is host-side as in the reference: `imageio` (libx264) when it is installed; this image has
-neither imageio nor an encoder, so the frames are then written as a raw `.npy` next to the requested
-name instead of being dropped."""
+encode is host-side as in the reference: `imageio` (libx264) when it is installed.  This image has
+neither imageio nor an H.264 encoder: the requested .mp4 is then written by `mp4_mjpeg.write_mp4_mjpeg`
+— a plain ISO base media file whose video track carries one JPEG per frame (PIL), readable by every
+libavformat-based player; any other suffix, or no PIL either, leaves the uint8 frames as a `.npy`."""
 import binascii
 import logging
 import os
@@ -43,10 +44,17 @@ def cache_video(tensor, save_file=None, fps=30, suffix='.mp4', nrow=8, normalize
     try:
         import imageio
     except ModuleNotFoundError:
+        if osp.splitext(cache_file)[1].lower() in ('.mp4', '.m4v', '.mov'):
+            try:
+                from .mp4_mjpeg import write_mp4_mjpeg
+                write_mp4_mjpeg(cache_file, frames, fps=fps)
+                logging.info(f'cache_video: imageio is not installed, wrote {frames.shape[0]} JPEG frames into {cache_file} (mp4v / Motion-JPEG, not H.264)')
+                return cache_file
+            except ModuleNotFoundError:          # no PIL either
+                pass
         path = osp.splitext(cache_file)[0] + '.npy'
         np.save(path, frames)
-        logging.info(f'cache_video: imageio is not installed, wrote the uint8 frames {frames.shape} to {path} '
-                     '(the mp4 container encode is host-side and outside this engine)')
+        logging.info(f'cache_video: neither imageio nor PIL is installed, wrote the uint8 frames {frames.shape} to {path}')
         return path
     error = None
     for _ in range(retry):

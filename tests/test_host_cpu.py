@@ -437,3 +437,51 @@ def test_sp_group_chooser_on_the_baseline_shapes():
     assert attention_rounds(40, 131040) == 80 and attention_rounds(1, 300) == 1
     # the explicit setting still wins (HeadExchange reads MOVIIGEN_SP_GROUPS) and sizes differ by at most one
     assert [n for _, n in split_heads(10, 4)] == [3, 3, 2, 2]
+
+
+def test_mp4_mjpeg_container(tmp_path):
+    """wan/utils/mp4_mjpeg.py — what `cache_video` writes when imageio is absent (reference wan/utils/utils.py:23-60 hands the frames to
+    imageio / libx264).  The file must be a well-formed ISO base media file: ftyp | mdat | moov in that order, every box size exact, the one chunk
+    offset pointing at a JPEG start-of-image, the sample sizes summing to the mdat payload, mp4v + objectTypeIndication 0x6C, the frame rate in
+    the media timescale — and the pictures must decode back to the frames (JPEG quality 95, 4:4:4)."""
+    import struct
+    from wan.utils import mp4_mjpeg as M
+    yy, xx = np.mgrid[0:50, 0:86]
+    frames = np.stack([np.stack([(xx * 3 + t * 10) % 256, (yy * 5 + t * 7) % 256, ((xx + yy) * 2 + t) % 256], -1) for t in range(5)]).astype(np.uint8)
+    for fps, fr in ((16, frames), (23.976, frames[:1]), (30, frames[:, :17, :33])):        # odd sizes, a single frame, a fractional rate
+        path = str(tmp_path / f'v{fps}.mp4')
+        n = M.write_mp4_mjpeg(path, fr, fps=fps)
+        buf = open(path, 'rb').read()
+        assert n == len(buf)
+        top = list(M._walk(buf, 0, len(buf)))
+        assert [k for k, _, _ in top] == [b'ftyp', b'mdat', b'moov'] and top[-1][2] == len(buf)
+        assert buf[8:12] == b'isom'
+        (_, ma, mb) = top[1]
+        sa, sb = M._find(buf, 0, len(buf), b'moov', b'trak', b'mdia', b'minf', b'stbl')
+        oa, _ = M._find(buf, sa, sb, b'stco')
+        count, off = struct.unpack_from('>II', buf, oa + 4)
+        assert count == 1 and off == ma and buf[off:off + 2] == b'\xff\xd8'
+        za, _ = M._find(buf, sa, sb, b'stsz')
+        fixed, cnt = struct.unpack_from('>II', buf, za + 4)
+        sizes = struct.unpack_from(f'>{cnt}I', buf, za + 12)
+        assert fixed == 0 and cnt == fr.shape[0] and sum(sizes) == mb - ma
+        pos = off
+        for sz in sizes:                                        # every sample is one whole JPEG
+            assert buf[pos:pos + 2] == b'\xff\xd8' and buf[pos + sz - 2:pos + sz] == b'\xff\xd9'
+            pos += sz
+        with pytest.raises(ValueError):
+            M._find(buf, sa, sb, b'stss')                       # no sync-sample table: every sample is a sync sample
+        back = M.read_mp4_mjpeg(path)
+        assert (back['codec'], back['object_type'], back['width'], back['height']) == ('mp4v', 0x6C, fr.shape[2], fr.shape[1])
+        assert abs(back['fps'] - fps) < 1e-3
+        assert back['frames'].shape == fr.shape
+        err = np.abs(back['frames'].astype(np.int32) - fr.astype(np.int32))
+        assert err.mean() < 2.0 and err.max() < 48, (err.mean(), err.max())
+        ha, _ = M._find(buf, 0, len(buf), b'moov', b'mvhd')
+        timescale, duration = struct.unpack_from('>II', buf, ha + 12)
+        assert timescale == 1000 and duration == round(fr.shape[0] * 1000.0 / fps)
+    for bad in (frames.astype(np.float32), frames[0], frames[:0]):
+        with pytest.raises(ValueError):
+            M.write_mp4_mjpeg(str(tmp_path / 'bad.mp4'), bad)
+    with pytest.raises(ValueError):
+        M.write_mp4_mjpeg(str(tmp_path / 'bad.mp4'), frames, fps=0)
