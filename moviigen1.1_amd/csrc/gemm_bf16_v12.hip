@@ -250,8 +250,15 @@ __global__ __launch_bounds__(V11_THREADS, 1) void gemm_bf16_v12_kernel(
         V12_SB;
         if (PROF) { const unsigned long long tt = __builtin_amdgcn_s_memtime(); ps[1] += tt - tsg; tsg = tt; }
         // ---- epilogue (gemm_v11_common.h) ----
-        if constexpr (PAIRED)
-            v11_epilogue_pair<EPI>(acc, m0 + wm * 128, n0 + wn * 128, r16, G, (flags & 4) ? 0 : M, N, bias, out, ldo);      // flags & 4: measurement without the stores
+        if constexpr (PAIRED) {
+#ifdef MG_AB_BUILD
+            if (flags & 1024)       // measurement: the tile's stores without the non-temporal hint
+                v11_epilogue_pair<EPI, false>(acc, m0 + wm * 128, n0 + wn * 128, r16, G, M, N, bias, out, ldo);
+            else
+#endif
+            // the tile is written once and read by another kernel: non-temporal stores (qkv +0.9 %, ffn.0 +1.6 %, N = 5120 unchanged: profiles/r05y4_gemm_pair_nt.log)
+            v11_epilogue_pair<EPI, true>(acc, m0 + wm * 128, n0 + wn * 128, r16, G, (flags & 4) ? 0 : M, N, bias, out, ldo);      // flags & 4: measurement without the stores
+        }
         else {
             const int64_t m_wave = m0 + wm * 128;
             const int n_wave = n0 + wn * 128;
@@ -330,7 +337,7 @@ int mg_gemm_v2_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_
                       int epilogue, void* out, int64_t ldo, const float* gate, hipStream_t st);      // gemm_bf16_v2.hip
 
 #ifdef MG_AB_BUILD
-static int g_v12_flags = 0;     // measurement bits (mg_gemm_set_variant(200 + flags)): 1 = fp32 outputs: residual batches not pipelined, 2 = raster 0 always, 4 = no stores (timing only), 8 = touch loads in front of the gated-residual epilogue, 128 = fp32 outputs: no residual loads (timing only), 256 / 512 = fp32 outputs: no nt hint on the stores / the residual loads, 16 = fp32 outputs: direct epilogue, 32 * (1 + s) = generated body s (0 / 2)
+static int g_v12_flags = 0;     // measurement bits (mg_gemm_set_variant(200 + flags)): 1 = fp32 outputs: residual batches not pipelined, 2 = raster 0 always, 4 = no stores (timing only), 8 = touch loads in front of the gated-residual epilogue, 128 = fp32 outputs: no residual loads (timing only), 256 / 512 = fp32 outputs: no nt hint on the stores / the residual loads, 1024 = bf16 outputs: no nt hint on the stores, 16 = fp32 outputs: direct epilogue, 32 * (1 + s) = generated body s (0 / 2)
 void mg_gemm_v12_set_flags(int f) { g_v12_flags = f; }
 #else
 static constexpr int g_v12_flags = 0;

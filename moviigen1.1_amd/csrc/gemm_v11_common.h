@@ -59,7 +59,7 @@ MG_DEV void v11_set_m0(unsigned lds_base) {
 MG_DEV int v11_feature_of_row(int row) {       // LDS row 16i + 4g + e of the W tile holds feature 32 (i >> 1) + 8g + 4 (i & 1) + e
     return (row & ~31) | ((row & 12) << 1) | ((row & 16) >> 2) | (row & 3);
 }
-template <int EPI, bool FULL, bool FULLM>
+template <int EPI, bool FULL, bool FULLM, bool NT = false>
 MG_DEV void v11_epilogue_pair_impl(const f32x4_t (&acc)[8][8], int64_t m_wave, int n_wave, int r16, int G, int64_t M, int N,
                                    const float* __restrict__ bias, void* __restrict__ out, int64_t ldo) {
     static_assert(EPI == MG_EPI_BIAS_BF16 || EPI == MG_EPI_BIAS_GELU_BF16, "bf16 outputs only");
@@ -109,7 +109,8 @@ MG_DEV void v11_epilogue_pair_impl(const f32x4_t (&acc)[8][8], int64_t m_wave, i
                 q.y = pack_bf2(v[2], v[3]);
                 q.z = pack_bf2(v[4], v[5]);
                 q.w = pack_bf2(v[6], v[7]);
-                *(uint4*)o = q;
+                if (NT) __builtin_nontemporal_store((u32x4_t){q.x, q.y, q.z, q.w}, (u32x4_t*)o);      // the non-temporal hint (variant 12; variant 11 stores plainly)
+                else *(uint4*)o = q;
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
@@ -118,12 +119,12 @@ MG_DEV void v11_epilogue_pair_impl(const f32x4_t (&acc)[8][8], int64_t m_wave, i
         }
     }
 }
-template <int EPI>
+template <int EPI, bool NT = false>
 MG_DEV void v11_epilogue_pair(const f32x4_t (&acc)[8][8], int64_t m_wave, int n_wave, int r16, int G, int64_t M, int N,
                               const float* __restrict__ bias, void* __restrict__ out, int64_t ldo) {
     // wave-uniform fast paths, as in mg_gemm_epilogue16
     if (n_wave + 128 <= N && m_wave + 128 <= M)
-        v11_epilogue_pair_impl<EPI, true, true>(acc, m_wave, n_wave, r16, G, M, N, bias, out, ldo);
+        v11_epilogue_pair_impl<EPI, true, true, NT>(acc, m_wave, n_wave, r16, G, M, N, bias, out, ldo);
     else if (n_wave + 128 <= N)
         v11_epilogue_pair_impl<EPI, true, false>(acc, m_wave, n_wave, r16, G, M, N, bias, out, ldo);
     else
