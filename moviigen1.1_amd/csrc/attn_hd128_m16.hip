@@ -398,7 +398,7 @@ __global__ __launch_bounds__(M16_THREADS, 1) void attn_hd128_m16_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, qi = lane & 15, G = lane >> 4;
     // persistent work loop over (head, query block) items, head-major.  Items are handed out by TICKET (`tickets` != nullptr): the first nwg
-    // items by workgroup index, every further one by an atomic counter, fetched one item ahead.  The static partition this replaces — XCD x owns
+    // items by workgroup index, every further one by an atomic counter, fetched one item ahead.  The static partition it replaces for long launches — XCD x owns
     // items [x, x + 1) * total / 8 — lost 2.0 % of the metric's launch to its tail: the 32 workgroups of an XCD end within 2 us of each other,
     // but the XCDs do not run at one speed (223.7 ms for the slowest, 211.0 ms for the fastest: profiles/r05v_attn_balance.log).  In ticket
     // order the XCD's workgroups still take neighbouring query blocks of one head at nearly the same moment and walk its K / V together.
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(M16_THREADS, 1) void attn_hd128_m16_kernel(
     int item, item_end, item_step;
     if (nwg == total_items || ticketed) {
         item = bid, item_end = ticketed ? total_items : bid + 1, item_step = 1;
-    } else {            // (measurement: the static, XCD-contiguous partition)
+    } else {            // the static, XCD-contiguous partition: launches of fewer than 32 rounds (mg_attn_m16_launch)
         const int xcd = bid & 7, slot = bid >> 3;
         item = (int)((int64_t)xcd * total_items / 8) + slot;
         item_end = (int)((int64_t)(xcd + 1) * total_items / 8);
