@@ -162,7 +162,7 @@ void mg_gemm_v12_set_flags(int f);
 extern "C" int mg_gemm_set_variant(int v) {      // 110 + f / 200 + f: variant 11 / 12 with measurement flags f (gemm_bf16_v11.hip, gemm_bf16_v12.hip)
     const int base = v >= 200 ? 12 : v >= 110 ? 11 : v;
     if (base != 0 && base != 1 && base != 2 && base != 7 && base != 8 && base != 11 && base != 12) return MG_ERR_ARG;      // no silent aliases
-    if ((v >= 110 && v - 110 >= 64 && v < 200) || v >= 200 + 2048) return MG_ERR_ARG;
+    if ((v >= 110 && v - 110 >= 64 && v < 200) || v >= 200 + 8192) return MG_ERR_ARG;
     g_gemm_variant = base;
     mg_gemm_v11_set_flags(v >= 110 && v < 200 ? v - 110 : 0);
     mg_gemm_v12_set_flags(v >= 200 ? v - 200 : 0);
