@@ -41,6 +41,22 @@ def test_cabi_exports_every_declared_symbol():
         assert exported == want, (path, exported ^ want)      # nothing undeclared leaks out, nothing declared is missing
 
 
+def test_ab_library_switches_refuse_unknown_numbers():
+    """the A/B library's kernel-selection switches are host-side bookkeeping (no GPU needed): numbers that name a kernel or a measurement build are
+    accepted, everything else is refused with MG_ERR_ARG instead of being aliased to some kernel; the scope resets them."""
+    from wan.backend import lib
+    with lib.ab_library() as h:
+        for v in (0, 1, 2, 7, 8, 11, 12, 110, 173, 200, 208, 232, 296, 968, 1224, 4296):      # 0 = the product's rule by shape
+            assert h.mg_gemm_set_variant(v) == 0, v
+        for v in (-1, 3, 4, 5, 6, 9, 10, 13, 99, 174, 199, 200 + 8192, 1 << 20):
+            assert h.mg_gemm_set_variant(v) != 0, v
+        assert h.mg_gemm_set_variant(lib.DEFAULT_GEMM_VARIANT) == 0
+        for v in (0, 3):
+            assert h.mg_attn_set_variant(v) == 0, v
+        for v in (-1, 1, 2, 4, 16):
+            assert h.mg_attn_set_variant(v) != 0, v
+
+
 def test_product_never_imports_oracle():
     pkg = os.path.join(ROOT, 'moviigen1.1_amd')
     for dp, _, fns in os.walk(pkg):
