@@ -383,11 +383,11 @@ int mg_gemm_set_variant(int variant);
  * Returns MG_ERR_ARG for anything else. */
 int mg_attn_set_variant(int variant);
 
-void mg_attn_w64_profile(unsigned long long* dev_buf);     /* both attention kernels: 4 waves x {fence, step A, step B, iterations} */
+void mg_attn_w64_profile(unsigned long long* dev_buf);     /* both attention kernels: 4 waves x {fence, step A, step B, iterations} at [0, 16); the m16 kernel also stores every workgroup's {start, end} (s_memrealtime) of the last launch at [16 + 2 b]: dev_buf holds 16 + 2 x 512 entries */
 void mg_attn_w64_debug(int flags);                         /* bit 0: keep the pipelined result of flagged blocks (no exact pass) */
 void mg_attn_w64_flag_counter(unsigned* dev_counter);      /* dev_counter[2]: [0] += query blocks whose pipelined pass flagged (m16: repeated with swept row maxima; w64: redone by the exact loop), [1] += m16 blocks that went on to the exact loop */
 void mg_gemm_debug_profile(unsigned long long* dev_buf);   /* GEMM variants 1/2: 8 waves x {wait+barrier, stage issue, MFMA, k-tiles} */
-void mg_gemm5_debug_profile(unsigned long long* dev_buf);  /* GEMM variants 7 / 8 / 11 / 12: per-wave s_memtime sums (csrc/tools/selftest.cpp gemmprof prints each layout) */
+void mg_gemm5_debug_profile(unsigned long long* dev_buf);  /* GEMM variants 7 / 8 / 11 / 12: per-wave s_memtime sums at [0, 64) (csrc/tools/selftest.cpp gemmprof prints each layout); variant 12 also stores every workgroup's {start, end} (s_memrealtime) at [64 + 2 b]: dev_buf holds 64 + 2 x 512 entries */
 #endif /* MG_AB_BUILD */
 
 #ifdef __cplusplus
