@@ -122,7 +122,8 @@ def _np_lincomb(like, terms):
     return acc
 
 
-@pytest.mark.parametrize('name,n,shift', [('unipc', 6, 3.0), ('unipc', 2, 5.0), ('dpm', 6, 3.0), ('dpm', 2, 5.0)])
+@pytest.mark.parametrize('name,n,shift', [('unipc', 6, 3.0), ('unipc', 2, 5.0), ('dpm', 6, 3.0), ('dpm', 2, 5.0),
+                                          ('unipc', 50, 5.0), ('dpm', 50, 5.0)])
 def test_scheduler_host_logic_vs_reference(golden, name, n, shift):
     """product schedulers (coefficient algebra on the host) driven with a CPU lincomb injected by
     the test: must follow the reference's trajectories (the GPU run of the same thing is in
@@ -142,11 +143,17 @@ def test_scheduler_host_logic_vs_reference(golden, name, n, shift):
         ts, _ = retrieve_timesteps(s, device='cpu', sigmas=get_sampling_sigmas(n, shift))
         assert np.array_equal(s.sigmas.numpy(), g[f'dpm_sigma_{n}'])
     assert np.array_equal(ts.numpy(), g[f'{name}_t_{n}'])
+    # (50, 5.0) = the production setting (text2video.py:114-124): all 50 steps of the reference's trajectory
+    g9 = golden('g9_sampling50')
+    traj = g9[f'traj_{name}'] if n == 50 else g[f'traj_{name}_{n}']
+    if n == 50:
+        assert np.array_equal(ts.numpy(), g9[f'{name}_t']) and len(traj) == 50
     lat = torch.from_numpy(g['traj_x0']).clone()
+    assert np.array_equal(g['traj_x0'], g9['traj_x0'])
     for i, t in enumerate(ts):
         v = 0.5 * torch.tanh(lat) + 0.1 * torch.sin(t.float() / 100.0)
         lat = s.step(v, t, lat, return_dict=False)[0]
-        ref = torch.from_numpy(g[f'traj_{name}_{n}'][i])
+        ref = torch.from_numpy(traj[i])
         assert ((lat - ref).abs().max() / ref.abs().max()).item() < 5e-6, (name, i)
 
 

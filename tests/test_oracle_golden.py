@@ -91,20 +91,26 @@ def test_scheduler_tables(golden):
     assert list(g['dpm_t_50'][:3]) == [1000, 995, 991]
 
 
-@pytest.mark.parametrize('name,n,shift', [('unipc', 6, 3.0), ('unipc', 2, 5.0), ('dpm', 6, 3.0), ('dpm', 2, 5.0)])
+@pytest.mark.parametrize('name,n,shift', [('unipc', 6, 3.0), ('unipc', 2, 5.0), ('dpm', 6, 3.0), ('dpm', 2, 5.0),
+                                          ('unipc', 50, 5.0), ('dpm', 50, 5.0)])
 def test_scheduler_trajectories(golden, name, n, shift):
-    g = golden('g4_schedulers')
+    """(50, 5.0) is the production setting (text2video.py:114-124): every one of the 50 steps of the reference's
+    trajectory is in g9_sampling50 (order ramp-up at step 1, lower_order_final at the end)."""
+    g = golden('g9_sampling50' if n == 50 else 'g4_schedulers')
     if name == 'unipc':
         s = schedulers.UniPCOracle(shift=1.0)
         ts = s.set_timesteps(n, shift=shift)
     else:
         s = schedulers.DPMppOracle()
         ts = s.set_timesteps(n, shift)
+    traj = g[f'traj_{name}'] if n == 50 else g[f'traj_{name}_{n}']
+    if n == 50:
+        assert np.array_equal(ts.numpy(), g[f'{name}_t']) and len(traj) == 50
     lat = T(g['traj_x0']).clone()
     for i, t in enumerate(ts):
         v = 0.5 * torch.tanh(lat) + 0.1 * torch.sin(t.float() / 100.0)
         lat = s.step(v, lat)
-        assert maxerr(lat, g[f'traj_{name}_{n}'][i]) < 2e-6, (name, i)
+        assert maxerr(lat, traj[i]) < 2e-6, (name, i)
 
 
 def test_vae_pieces(golden):
@@ -229,3 +235,29 @@ def test_rope_apply_dist(golden):
     x = T(g['rope_dist_x'])[0]
     for r in range(2):
         assert maxerr(dit.rope(x, grid, tabs, pos0=r * x.shape[0]), g[f'rope_dist_rank{r}'][0]) < 1e-6
+
+
+@pytest.mark.parametrize('solver', ['unipc', 'dpm++'])
+def test_generate_loop_50_steps(golden, solver):
+    """The oracle at the PRODUCTION sampling setting: the loop body of text2video.py:233-254 (two DiT forwards, CFG 5.0,
+    scheduler step) for N = 50, shift 5.0 on the small head-dim-128 DiT, fp32, against the imported reference's latents
+    after steps 1, 10, 20, 30, 40, 50 (tests/golden/make_golden_sampling50.py)."""
+    g = golden('g9_sampling50')
+    cfg = W.SMALL_DIT_HD128
+    P = W.make_dit_params(cfg, 0)
+    if solver == 'unipc':
+        s = schedulers.UniPCOracle(shift=1.0)
+        ts = s.set_timesteps(50, shift=5.0)
+    else:
+        s = schedulers.DPMppOracle()
+        ts = s.set_timesteps(50, 5.0)
+    lat, ctx, ctxn = T(g['noise']), T(g['ctx']), T(g['ctx_null'])
+    keep = list(g['keep'])
+    for i, t in enumerate(ts):
+        tt = t.reshape(1)
+        c = dit.dit_forward(P, cfg, lat, tt, ctx, 48)
+        u = dit.dit_forward(P, cfg, lat, tt, ctxn, 48)
+        lat = s.step((u + 5.0 * (c - u))[None], lat[None])[0]
+        if i + 1 in keep:
+            ref = T(g[f'lat_{solver}_fp32'][keep.index(i + 1)])
+            assert ((lat - ref).norm() / ref.norm()).item() < 2e-5, (solver, i + 1)
