@@ -108,10 +108,18 @@ int mg_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw,
  * wan/modules/attention.py:96-127 (self-attention model.py:146-151, k_lens=seq_lens;
  * cross-attention model.py:176, Lk = 512 unmasked).
  *   q [Lq][>=heads*128] row stride ldq, head h at column h*128; o likewise (row stride ldo)
- *   kp, vp: K and V of the Lk keys packed by mg_pack_kv_bf16(…, L = Lk, …). */
+ *   kp, vp: K and V of the Lk keys packed by mg_pack_kv_bf16(…, L = Lk, …).
+ *   workspace: NULL, or mg_attn_workspace_bytes() device bytes OWNED BY THE CALLER, 8-byte aligned, zeroed once before
+ *     their first use.  A persistent launch with >= 32 rounds of work per compute unit hands its (query block, head)
+ *     items out by ticket through it (+1.35 % at the metric's launch) and leaves it zeroed when it ends, so launches
+ *     that are ordered with respect to one another (one stream, or event-ordered) share one workspace; launches that may
+ *     overlap need one each.  With NULL the launch uses the static per-XCD partition (same bits).  The library holds no
+ *     device memory of its own and never allocates or synchronises inside a launch; a launch with a
+ *     workspace is capturable in a hipGraph from its first call. */
+int64_t mg_attn_workspace_bytes(void);
 int mg_attn_fwd_bf16_hd128(const uint16_t* q, int64_t ldq, const uint16_t* kp, const uint16_t* vp,
                            uint16_t* o, int64_t ldo, int64_t Lq, int64_t Lk, int heads, float scale,
-                           void* stream);
+                           void* workspace, void* stream);
 
 /* Same contract for any head_dim <= 256 (head_dim % 8 == 0): the correctness path for model
  * sizes whose head_dim is not 128 (BASELINE.json configs[0]: head_dim 32).  v is NOT transposed:
@@ -120,7 +128,7 @@ int mg_attn_fwd_bf16_hd128(const uint16_t* q, int64_t ldq, const uint16_t* kp, c
  * NULL = mg_attn_fwd_bf16_hd128).  Ring attention merges per-block results with it. */
 int mg_attn_fwd_bf16_hd128_lse(const uint16_t* q, int64_t ldq, const uint16_t* kp, const uint16_t* vp,
                                uint16_t* o, int64_t ldo, float* lse, int64_t Lq, int64_t Lk, int heads,
-                               float scale, void* stream);
+                               float scale, void* workspace, void* stream);
 
 /* Same operator for a q that ALREADY carries the factor scale*log2(e) (mg_rmsnorm_rope_bf16 with out_scale: the factor
  * enters before q's one rounding to bf16, so nothing is rounded twice) — the form WanModel.forward uses.  With the
@@ -131,7 +139,7 @@ int mg_attn_fwd_bf16_hd128_lse(const uint16_t* q, int64_t ldq, const uint16_t* k
  * parallelism: a persistent workgroup holds its CU's whole register file until the launch ends).  0 = all CUs. */
 int mg_attn_fwd_bf16_hd128_prescaled(const uint16_t* q, int64_t ldq, const uint16_t* kp, const uint16_t* vp,
                                      uint16_t* o, int64_t ldo, float* lse, int64_t Lq, int64_t Lk, int heads,
-                                     int reserve_cus, void* stream);
+                                     int reserve_cus, void* workspace, void* stream);
 
 /* x[r][c] += float(y[r][c]) * gate[c]: the gated residual update of wan/modules/model.py:301-302,306,308-309 as a
  * stand-alone kernel (x fp32 [rows][dim] row stride ldx; y bf16 row stride ldy; gate fp32 [dim] or NULL = 1).

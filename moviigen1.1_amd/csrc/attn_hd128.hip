@@ -74,7 +74,7 @@ int mg_attn_w64_launch(const uint16_t* q, int64_t ldq, const uint16_t* kp, const
 #endif
 int mg_attn_m16_launch(const uint16_t* q, int64_t ldq, const uint16_t* kp, const uint16_t* vp, uint16_t* o, int64_t ldo,
                        int64_t Lq, int64_t Lk, int heads, float c_log2, int prescaled, int nqb, float* lse, int reserve_cus,
-                       hipStream_t st);
+                       unsigned* workspace, hipStream_t st);
 
 // The product library has ONE head-dim-128 kernel (m16) and no switch.  The A/B library (-DMG_AB_BUILD) adds the round-2 kernel (w64, NOT the
 // same bits) behind mg_attn_set_variant — a process-global measurement switch that also selects the K row order mg_pack_kv_bf16 writes.
@@ -100,8 +100,10 @@ extern "C" int mg_pack_kv_bf16(const uint16_t* k, int64_t ldk, const uint16_t* v
 }
 
 static int attn_fwd_impl(const uint16_t* q, int64_t ldq, const uint16_t* kp, const uint16_t* vp, uint16_t* o, int64_t ldo,
-                         float* lse, int64_t Lq, int64_t Lk, int heads, float scale, int prescaled, int reserve_cus, void* stream) {
+                         float* lse, int64_t Lq, int64_t Lk, int heads, float scale, int prescaled, int reserve_cus, void* workspace,
+                         void* stream) {
     if (!q || !kp || !vp || !o) return MG_ERR_ARG;
+    if ((uintptr_t)workspace & 7) return MG_ERR_SHAPE;
     if (Lq < 0 || Lk <= 0 || heads <= 0 || reserve_cus < 0) return MG_ERR_SHAPE;
     if ((ldq & 7) || (ldo & 3)) return MG_ERR_SHAPE;
     if (((uintptr_t)q & 15) || ((uintptr_t)kp & 15) || ((uintptr_t)vp & 15) || ((uintptr_t)o & 7)) return MG_ERR_SHAPE;
@@ -115,21 +117,24 @@ static int attn_fwd_impl(const uint16_t* q, int64_t ldq, const uint16_t* kp, con
     if (g_attn_variant == 3)    // the round-2 kernel knows no pre-scaled q other than "its own factor is 1"
         return mg_attn_w64_launch(q, ldq, kp, vp, o, ldo, Lq, Lk, heads, prescaled ? 1.0f : c_log2, nqb, lse, st);
 #endif
-    return mg_attn_m16_launch(q, ldq, kp, vp, o, ldo, Lq, Lk, heads, c_log2, prescaled, nqb, lse, reserve_cus, st);
+    return mg_attn_m16_launch(q, ldq, kp, vp, o, ldo, Lq, Lk, heads, c_log2, prescaled, nqb, lse, reserve_cus, (unsigned*)workspace, st);
 }
+
+// bytes of the caller-owned, zero-initialised workspace of mg_attn_fwd_bf16_hd128* (one {next ticket, workgroups done} pair, padded)
+extern "C" int64_t mg_attn_workspace_bytes(void) { return 256; }
 
 extern "C" int mg_attn_fwd_bf16_hd128_lse(const uint16_t* q, int64_t ldq, const uint16_t* kp, const uint16_t* vp,
                                           uint16_t* o, int64_t ldo, float* lse, int64_t Lq, int64_t Lk, int heads,
-                                          float scale, void* stream) {
-    return attn_fwd_impl(q, ldq, kp, vp, o, ldo, lse, Lq, Lk, heads, scale, 0, 0, stream);
+                                          float scale, void* workspace, void* stream) {
+    return attn_fwd_impl(q, ldq, kp, vp, o, ldo, lse, Lq, Lk, heads, scale, 0, 0, workspace, stream);
 }
 extern "C" int mg_attn_fwd_bf16_hd128(const uint16_t* q, int64_t ldq, const uint16_t* kp, const uint16_t* vp,
                                       uint16_t* o, int64_t ldo, int64_t Lq, int64_t Lk, int heads, float scale,
-                                      void* stream) {
-    return attn_fwd_impl(q, ldq, kp, vp, o, ldo, nullptr, Lq, Lk, heads, scale, 0, 0, stream);
+                                      void* workspace, void* stream) {
+    return attn_fwd_impl(q, ldq, kp, vp, o, ldo, nullptr, Lq, Lk, heads, scale, 0, 0, workspace, stream);
 }
 extern "C" int mg_attn_fwd_bf16_hd128_prescaled(const uint16_t* q, int64_t ldq, const uint16_t* kp, const uint16_t* vp,
                                                 uint16_t* o, int64_t ldo, float* lse, int64_t Lq, int64_t Lk, int heads,
-                                                int reserve_cus, void* stream) {
-    return attn_fwd_impl(q, ldq, kp, vp, o, ldo, lse, Lq, Lk, heads, 1.0f, 1, reserve_cus, stream);
+                                                int reserve_cus, void* workspace, void* stream) {
+    return attn_fwd_impl(q, ldq, kp, vp, o, ldo, lse, Lq, Lk, heads, 1.0f, 1, reserve_cus, workspace, stream);
 }

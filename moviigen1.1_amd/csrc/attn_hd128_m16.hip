@@ -37,8 +37,6 @@
 // softmax costs exp + add + half a cvt_pk per score.  SCALED = true (any q, any scale): one v_mul more per score, q is
 // used as given (no second rounding); the reference is kept in raw score units either way.
 #include <type_traits>
-#include <atomic>
-#include <mutex>
 #include "common.h"
 #include "../../include/moviigen_hip.h"
 
@@ -783,28 +781,10 @@ __global__ __launch_bounds__(M16_THREADS, 1) void attn_hd128_m16_kernel(
     if (PROF && prof && tid == 0) prof[16 + 2 * bid] = r_start, prof[16 + 2 * bid + 1] = __builtin_amdgcn_s_memrealtime();      // the last launch's {start, end} per workgroup
 }
 
-// Ticket counters of the persistent launches: a ring of {next ticket, workgroups done} pairs per device, zero when idle (a launch leaves its
-// pair zeroed).  Every launch takes the next pair: launches in flight on different streams never share one (the ring is far longer than any
-// queue of attention launches), and a captured launch that is replayed finds its pair re-armed by its previous run.
-#define M16_TICKET_SLOTS 4096
-static unsigned* g_m16_ticket_ring[16] = {};
-static std::atomic<unsigned> g_m16_ticket_next{0};
-static std::mutex g_m16_ticket_mutex;
-static unsigned* m16_ticket_pair() {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    if (!g_m16_ticket_ring[dev]) {
-        std::lock_guard<std::mutex> lock(g_m16_ticket_mutex);
-        if (!g_m16_ticket_ring[dev]) {
-            unsigned* p = nullptr;
-            if (hipMalloc(&p, M16_TICKET_SLOTS * 2 * sizeof(unsigned)) != hipSuccess) return nullptr;
-            if (hipMemset(p, 0, M16_TICKET_SLOTS * 2 * sizeof(unsigned)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return nullptr;
-            g_m16_ticket_ring[dev] = p;
-        }
-    }
-    return g_m16_ticket_ring[dev] + 2 * (g_m16_ticket_next.fetch_add(1) % M16_TICKET_SLOTS);
-}
-
+// Ticket counters of the persistent launches: ONE pair {next ticket, workgroups done} in the CALLER's workspace (mg_attn_workspace_bytes()
+// zero-initialised device bytes, include/moviigen_hip.h): zero when idle — the last workgroup of a launch re-arms it — so launches that are
+// ordered with respect to one another (one stream, or event-ordered) share it, and a captured launch that is replayed finds it re-armed by its
+// previous run.  The library allocates nothing and synchronises nothing here; with no workspace the launch uses the static per-XCD partition.
 static int g_m16_dbg = 0;
 static unsigned long long* g_m16_prof = nullptr;
 static unsigned* g_m16_flagcnt = nullptr;
@@ -818,7 +798,7 @@ void mg_attn_m16_hooks(int dbg, unsigned long long* prof, unsigned* flagcnt) { g
 // run on CUs this grid does not occupy.
 int mg_attn_m16_launch(const uint16_t* q, int64_t ldq, const uint16_t* kp, const uint16_t* vp, uint16_t* o, int64_t ldo,
                        int64_t Lq, int64_t Lk, int heads, float c_log2, int prescaled, int nqb, float* lse, int reserve_cus,
-                       hipStream_t st) {
+                       unsigned* workspace, hipStream_t st) {
     int n_cu = mg_cu_count();
     if (n_cu < 0) return MG_ERR_LAUNCH;
     n_cu &= ~7;                                         // one workgroup per CU (96 KiB LDS), a multiple of the 8 XCDs
@@ -829,10 +809,8 @@ int mg_attn_m16_launch(const uint16_t* q, int64_t ldq, const uint16_t* kp, const
     // Items by ticket from 32 rounds on (the metric's launch has 80: +1.35 %, 220.3 against 223.3 ms; 16 rounds: -0.2 %, and at the 10 rounds of
     // a sequence-parallel rank nobody has a spare item to take — profiles/r05w_attn_tickets.log); below that the static per-XCD partition.
     unsigned* tickets = nullptr;
-    if ((int64_t)total >= 32 * (int64_t)grid && !(g_m16_dbg & 16)) {      // (debug bit 4, A/B library: the static partition always)
-        tickets = m16_ticket_pair();
-        if (!tickets) return MG_ERR_LAUNCH;
-    }
+    if (workspace && (int64_t)total >= 32 * (int64_t)grid && !(g_m16_dbg & 16))      // (debug bit 4, A/B library: the static partition always)
+        tickets = workspace;
 #define M16_ORD 1      // the filler placement the library ships (m16_step): one v_exp_f32 per MFMA gap, alone (profiles/r05m_attn_order.log: +4.8 % over placement 0)
 #define M16_LAUNCH(PROF, SCALED, ORD)                                                                                             \
     hipLaunchKernelGGL((attn_hd128_m16_kernel<PROF, SCALED, ORD>), dim3(grid), dim3(M16_THREADS), 0, st, q, ldq, kp, vp, o, ldo, Lq, \

@@ -463,4 +463,4 @@ extern "C" int mg_gate_residual_f32(float* x, int64_t ldx, const uint16_t* y, in
 }
 
 extern "C" const char* mg_version(void) { return "moviigen_hip 3 gfx950"; }
-extern "C" int mg_abi_version(void) { return 8; }   // 8: the product library exports no kernel-selection switch and no profiling hook (they live in libmoviigen_hip_ab.so, -DMG_AB_BUILD; mg_*_set_variant return a status there); 7: the VAE arithmetic mode is an argument of mg_vae_conv_f32 / mg_vae_upconv_phases_f32 (mg_vae_set_mode is gone), mg_attn_w64_flag_counter counts into two words, mg_attn_fwd_bf16_hd128_prescaled gained reserve_cus; 6: + mg_vae_set_mode; 5: + mg_vae_upconv_fold_weights_f32 / mg_vae_upconv_phases_f32; 4: mg_rmsnorm_rope_bf16 gained out_scale, mg_pack_kv_bf16's K row order follows the 16x16x32 attention kernel, + mg_attn_fwd_bf16_hd128_prescaled
+extern "C" int mg_abi_version(void) { return 9; }   // 9: mg_attn_fwd_bf16_hd128 / _lse / _prescaled take a caller-owned workspace (mg_attn_workspace_bytes(); the library no longer allocates or synchronises on a launch path); 8: the product library exports no kernel-selection switch and no profiling hook (they live in libmoviigen_hip_ab.so, -DMG_AB_BUILD; mg_*_set_variant return a status there); 7: the VAE arithmetic mode is an argument of mg_vae_conv_f32 / mg_vae_upconv_phases_f32 (mg_vae_set_mode is gone), mg_attn_w64_flag_counter counts into two words, mg_attn_fwd_bf16_hd128_prescaled gained reserve_cus; 6: + mg_vae_set_mode; 5: + mg_vae_upconv_fold_weights_f32 / mg_vae_upconv_phases_f32; 4: mg_rmsnorm_rope_bf16 gained out_scale, mg_pack_kv_bf16's K row order follows the 16x16x32 attention kernel, + mg_attn_fwd_bf16_hd128_prescaled

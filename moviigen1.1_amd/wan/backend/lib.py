@@ -26,9 +26,10 @@ SIGNATURES = {
                              c_int, c_i64, c_f32, c_vp],
     'mg_pack_kv_bf16': [c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_int, c_vp, c_vp, c_vp],
     'mg_gemm_bf16': [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_int, c_vp, c_i64, c_vp, c_vp],
-    'mg_attn_fwd_bf16_hd128': [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_f32, c_vp],
-    'mg_attn_fwd_bf16_hd128_lse': [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_f32, c_vp],
-    'mg_attn_fwd_bf16_hd128_prescaled': [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_int, c_vp],
+    'mg_attn_workspace_bytes': [],
+    'mg_attn_fwd_bf16_hd128': [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_f32, c_vp, c_vp],
+    'mg_attn_fwd_bf16_hd128_lse': [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_f32, c_vp, c_vp],
+    'mg_attn_fwd_bf16_hd128_prescaled': [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_int, c_vp, c_vp],
     'mg_attn_merge_f32': [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_vp],
     'mg_attn_fwd_bf16_generic': [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_int, c_int,
                                  c_f32, c_vp],
@@ -77,7 +78,7 @@ SIGNATURES_AB = {
     'mg_gemm_debug_profile': [c_vp],
     'mg_gemm5_debug_profile': [c_vp],
 }
-_RESTYPE = {'mg_version': ctypes.c_char_p, 'mg_vae_attn_workspace_floats': ctypes.c_int64, 'mg_attn_w64_profile': None,
+_RESTYPE = {'mg_version': ctypes.c_char_p, 'mg_vae_attn_workspace_floats': ctypes.c_int64, 'mg_attn_workspace_bytes': ctypes.c_int64, 'mg_attn_w64_profile': None,
             'mg_attn_w64_debug': None, 'mg_attn_w64_flag_counter': None, 'mg_gemm_debug_profile': None, 'mg_gemm5_debug_profile': None}
 DEFAULT_GEMM_VARIANT = 0   # mg_gemm_set_variant(0) = the product's rule by shape (A/B library)
 

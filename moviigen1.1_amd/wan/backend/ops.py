@@ -84,20 +84,40 @@ def gemm(a, w, bias, epilogue, out, gate=None):
     return out
 
 
-def attention_hd128(q, kp, vp, out, lk, heads, scale, prescaled=False, reserve_cus=0):
+_ATTN_WS = {}
+
+
+def attention_workspace(device=None, stream=None):
+    """The caller-owned workspace of mg_attn_fwd_bf16_hd128* for launches on `stream` of `device` (default: the current ones):
+    mg_attn_workspace_bytes() zeroed bytes, allocated once per (device, stream) HERE — outside the library, which never
+    allocates — and shared by that stream's launches (they are ordered; each leaves it zeroed)."""
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    st = torch.cuda.current_stream(dev) if stream is None else stream
+    key = (dev, st.cuda_stream)
+    ws = _ATTN_WS.get(key)
+    if ws is None:
+        with torch.cuda.stream(st):
+            ws = torch.zeros(int(lib.load().mg_attn_workspace_bytes()), dtype=torch.uint8, device=f'cuda:{dev}')
+        _ATTN_WS[key] = ws
+    return ws
+
+
+def attention_hd128(q, kp, vp, out, lk, heads, scale, prescaled=False, reserve_cus=0, workspace='stream'):
     """q [Lq, >=heads*128] bf16; kp/vp from pack_kv for the same lk keys; out [Lq, >=heads*128].
     prescaled: q was produced with rmsnorm_rope(out_scale=scale * ATTN_LOG2E) — `scale` is then only documentation.
-    reserve_cus (prescaled entry): CUs the persistent grid leaves free for a kernel on another stream (the exchange)."""
+    reserve_cus (prescaled entry): CUs the persistent grid leaves free for a kernel on another stream (the exchange).
+    workspace: 'stream' = attention_workspace() of the current stream; a uint8 tensor of the caller's; None = no tickets."""
     _chk(q, torch.bfloat16, 'q'); _chk(kp, torch.bfloat16, 'kp'); _chk(vp, torch.bfloat16, 'vp')
     _chk(out, torch.bfloat16, 'out')
     if min(kp.numel(), vp.numel()) < packed_kv_numel(int(lk), int(heads)):
         raise lib.MoviigenHipError('packed K/V buffers too small for lk keys')
+    ws = attention_workspace(q.device) if isinstance(workspace, str) else workspace
     if prescaled:
         lib.call('mg_attn_fwd_bf16_hd128_prescaled', _p(q), q.stride(0), _p(kp), _p(vp), _p(out), out.stride(0), None,
-                 q.shape[0], int(lk), int(heads), int(reserve_cus), _st())
+                 q.shape[0], int(lk), int(heads), int(reserve_cus), _p(ws), _st())
     else:
         lib.call('mg_attn_fwd_bf16_hd128', _p(q), q.stride(0), _p(kp), _p(vp), _p(out), out.stride(0), q.shape[0],
-                 int(lk), int(heads), float(scale), _st())
+                 int(lk), int(heads), float(scale), _p(ws), _st())
     return out
 
 
@@ -336,12 +356,13 @@ def attention_hd128_lse(q, kp, vp, out, lse, lk, heads, scale, prescaled=False):
         raise lib.MoviigenHipError('packed K/V buffers too small for lk keys')
     if lse.numel() < int(heads) * q.shape[0] or not lse.is_contiguous():
         raise lib.MoviigenHipError('lse must be a contiguous [heads, Lq] fp32 tensor')
+    ws = attention_workspace(q.device)
     if prescaled:
         lib.call('mg_attn_fwd_bf16_hd128_prescaled', _p(q), q.stride(0), _p(kp), _p(vp), _p(out), out.stride(0), _p(lse),
-                 q.shape[0], int(lk), int(heads), 0, _st())
+                 q.shape[0], int(lk), int(heads), 0, _p(ws), _st())
     else:
         lib.call('mg_attn_fwd_bf16_hd128_lse', _p(q), q.stride(0), _p(kp), _p(vp), _p(out), out.stride(0), _p(lse),
-                 q.shape[0], int(lk), int(heads), float(scale), _st())
+                 q.shape[0], int(lk), int(heads), float(scale), _p(ws), _st())
     return out, lse
 
 

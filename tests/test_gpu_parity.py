@@ -719,9 +719,10 @@ def test_pipeline_cfg1(dev, golden, solver):
 
 # Stated end-to-end tolerances of the production sampling setting: rel-L2 of the latent against the
 # reference's fp32 loop.  The reference's OWN bf16-autocast run drifts 4.4e-5 / 3.6e-4 / 8.3e-4 / 1.6e-3 / 2.6e-3 / 3.9e-3
-# from its fp32 run at these steps (printed by make_golden_sampling50.py); the engine is allowed 3x that, and must stay
-# within 2x the reference's bf16 drift of the reference's bf16 run itself.
-DRIFT_BOUND_50 = {1: 2e-4, 10: 1.2e-3, 20: 2.5e-3, 30: 5e-3, 40: 8e-3, 50: 1.2e-2}
+# from its fp32 run at these steps (printed by make_golden_sampling50.py); the engine is allowed 1.65x that (measured,
+# profiles/r06_pytest_sampling50.log: 4.4e-5 ... 4.0e-3 = the reference's own drift), and must stay within the
+# reference's bf16 drift (+1e-4) of the reference's bf16 run itself (measured: half of it).
+DRIFT_BOUND_50 = {1: 1e-4, 10: 6e-4, 20: 1.4e-3, 30: 2.6e-3, 40: 4.5e-3, 50: 6.5e-3}
 
 
 @pytest.mark.parametrize('solver', ['unipc', 'dpm++'])
@@ -752,12 +753,12 @@ def test_pipeline_50_steps_drift(dev, golden, solver):
         print(f'{solver} step {step}: engine vs ref fp32 {e32:.2e}, vs ref bf16 {ebf:.2e}, ref bf16 vs fp32 '
               f'{ref_bf16_drift[j]:.2e}')
         assert e32 < DRIFT_BOUND_50[step], (solver, step, e32)
-        assert ebf < 2 * ref_bf16_drift[j] + 1e-4, (solver, step, ebf)
+        assert ebf < ref_bf16_drift[j] + 1e-4, (solver, step, ebf)
     assert tuple(video.shape) == (3, 5, 64, 96) and video.dtype == torch.float32
     if solver == 'unipc':
         ev = rel_l2(video, g['video_unipc_fp32'])
         print(f'video rel-L2 {ev:.2e}')
-        assert ev < 2e-2
+        assert ev < 1.2e-2
 
 
 # ------------------------------------------------------------------------------------------------
