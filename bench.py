@@ -7,8 +7,13 @@ two WanModel forwards (cond / uncond), the CFG combine and one UniPC scheduler s
 synthetic data of the configuration BASELINE.json's `metric` is quoted on: 14B T2V,
 1920x832x81f (latent [16,21,104,240], L = 131 040 tokens) — it fits one MI355X, so N=1 runs
 it unsharded (`--workload 720p` = BASELINE configs[1], 1280x720x81f, L = 75 600).
-N>1 (one rank per GPU): the SAME video sharded over the ranks — cond / uncond halves x Ulysses sequence parallelism
-over RCCL (`--no-cfg-parallel`: Ulysses over all N ranks) -> strong scaling.  Launched either by torch.distributed.run
+N>1 (one rank per GPU): the SAME video sharded over the ranks -> strong scaling.  The PRIMARY layout (`value`) is Ulysses sequence
+parallelism over all N ranks on RCCL — the reference's layout and what BASELINE configs[2] names ("Ulysses SP=8"); for even N the same run
+then measures the second layout — cond / uncond halves x Ulysses N/2 — with its own warm-up and K steps and reports it as `other_layout`
+(`--cfg-parallel` swaps the two, `--single-layout` skips the second; `--dit-fsdp` = BASELINE configs[3]: cfg2 x ulysses_sp(N/2) x fsdpN only).
+Before the warm-up a time-boxed PREFLIGHT (wan/distributed/preflight.py) records what the node can do: RCCL rank count, peer access per
+rank pair, a 64 MiB all-to-all on the exchange's default transport (`link_gbps_measured`) and — only when the copy-engine transport is asked
+for — IPC windows, self-check and the same exchange as peer copies.  Launched either by torch.distributed.run
 (the driver's form; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment) or PLAINLY — `python bench.py
 --gpus N` without WORLD_SIZE re-executes itself under torch.distributed.run on 127.0.0.1 (reference launch contract:
 scripts/inference/generate.py:190-229, one process per GPU + init_process_group("nccl")).  The N > 1 line additionally
@@ -298,8 +303,17 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-video-tail', action='store_true',
                     help='skip the VAE decode / T5 legs measured after the timed region (profiling passes)')
+    ap.add_argument('--cfg-parallel', action='store_true',
+                    help='N > 1, even: make cond / uncond halves x Ulysses N/2 the PRIMARY layout (`value`); by default the primary is Ulysses '
+                         "over all N ranks — the reference's layout and BASELINE configs[2] — and this one is measured second (`other_layout`)")
     ap.add_argument('--no-cfg-parallel', action='store_true',
-                    help='N > 1: Ulysses over all N ranks (the reference layout) instead of cond/uncond halves x Ulysses N/2')
+                    help='N > 1: Ulysses over all N ranks as the primary layout (the default since round 6; kept for the round-5 command lines)')
+    ap.add_argument('--single-layout', action='store_true', help='N > 1: measure the primary layout only (no `other_layout`)')
+    ap.add_argument('--preflight', default='auto', choices=['auto', 'full'],
+                    help="N > 1: the first-contact check before the warm-up (wan/distributed/preflight.py).  auto: ranks, peer access, a 64 MiB "
+                         "all-to-all on the default transport; the IPC / peer-copy probe only when that transport is asked for.  full: always")
+    ap.add_argument('--no-preflight', action='store_true')
+    ap.add_argument('--preflight-budget', type=float, default=60.0, help='seconds the preflight may take before it skips its remaining stages')
     ap.add_argument('--dit-fsdp', action='store_true',
                     help="N > 1: DiT block weights sharded over ALL N ranks and all-gathered one block ahead (the reference's "
                          '--dit_fsdp, wan/text2video.py:107-108 -> shard_model); with the default layout on 8 GPUs this is BASELINE '
@@ -377,32 +391,35 @@ def main():
     calib = None
     if world == 1 and not args.no_calibration and args.workload != 'tiny' and not args.layers:
         calib = box_calibration(dev, local)
-    model = wan.modules.WanModel(**cfg, device=dev)
-    model.init_weights(seed=0)
-    model.eval().requires_grad_(False)
-    cfgp = None
-    if world > 1:
-        # even N: cond / uncond halves, Ulysses inside each half (same math, less traffic: see
-        # wan/distributed/cfg_parallel.py); odd N or --no-cfg-parallel: Ulysses over all ranks
-        if world % 2 == 0 and not args.no_cfg_parallel:
-            from wan.distributed.cfg_parallel import enable_cfg_parallel
-            cfgp = enable_cfg_parallel(model)
-        else:
-            from wan.distributed.xdit_context_parallel import enable_sequence_parallel
-            enable_sequence_parallel(model)
-        if args.dit_fsdp:
-            from wan.distributed.fsdp import shard_model
-            shard_model(model, device_id=local)       # 1/N of every block's GEMM weights per rank, gathered one block ahead
-    sp = model.sp_size
+    # ---- N > 1: what this node / process group can do, measured before anything else (wan/distributed/preflight.py) -------------------
+    pre = None
+    if world > 1 and not args.no_preflight:
+        from wan.distributed import preflight
+        want_peer = (args.transport or os.environ.get('MOVIIGEN_SP_TRANSPORT') or 'torch') in ('auto', 'peer_copy') or args.preflight == 'full'
+        try:
+            pre = preflight.run(None, dev, probe_peer_copy=want_peer, budget_s=args.preflight_budget)
+        except Exception as e:      # noqa: BLE001 — the preflight must never be the reason a bench line is missing
+            pre = {'errors': [f'preflight: {type(e).__name__}: {e}'], 'rccl_ranks': 0 if os.environ.get('MOVIIGEN_BENCH_BACKEND') == 'gloo' else world}
+        if rank == 0:
+            print('preflight: ' + json.dumps(pre), file=sys.stderr, flush=True)
+
+    # ---- layouts of the N > 1 forward ---------------------------------------------------------------------------------------------------
+    #   'ulysses': Ulysses sequence parallelism over all N ranks — the reference's layout (scripts/inference/generate.py:216-229) and what
+    #              BASELINE configs[2] names ("Ulysses SP=8"): the PRIMARY line, `value`
+    #   'cfg'    : cond / uncond halves x Ulysses N/2 (wan/distributed/cfg_parallel.py: same math, half the exchange partners) — measured in
+    #              the same run and reported as `other_layout` (even N); primary only with --cfg-parallel, or with --dit-fsdp (BASELINE
+    #              configs[3]: "FSDP shard + SP=4 on 8 GPUs" = cfg2 x ulysses_sp4 x fsdp8)
+    even = world > 1 and world % 2 == 0
+    primary = 'single' if world == 1 else 'cfg' if even and (args.cfg_parallel or args.dit_fsdp) and not args.no_cfg_parallel else 'ulysses'
+    secondary = None
+    if even and not args.single_layout and not args.dit_fsdp:
+        secondary = 'ulysses' if primary == 'cfg' else 'cfg'
+
     g = torch.Generator(device=dev).manual_seed(42)
-    latent = torch.randn(*lat_shape, dtype=torch.float32, device=dev, generator=g)
+    latent0 = torch.randn(*lat_shape, dtype=torch.float32, device=dev, generator=g)
     ctx = torch.randn(512, 4096, device=dev, generator=g).bfloat16()
     ctx_null = torch.randn(130, 4096, device=dev, generator=g).bfloat16()
     total = args.warmup + args.steps
-    sch = FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)
-    sch.set_timesteps(50, device=dev, shift=5.0)
-    ts = sch.timesteps
-    ts_host = ts.tolist()
 
     # live timing of the dominant kernel (self-attention) on the launch stream
     attn_events = []
@@ -420,65 +437,117 @@ def main():
         return orig_attn(q, k, vt, out, lk, heads, scale, **kw)
     ops.attention_hd128 = timed_attn
 
-    noise_pred = torch.empty_like(latent)
-
-    def step(i):
-        nonlocal latent
-        t = ts[i:i + 1]
-        if cfgp is None:
-            cond = model([latent], t=t, context=[ctx], seq_len=L)[0]
-            uncond = model([latent], t=t, context=[ctx_null], seq_len=L)[0]
-        else:
-            mine = model([latent], t=t, context=[ctx_null if cfgp.branch else ctx], seq_len=L)[0]
-            cond, uncond = cfgp.exchange(mine)
-        ops.cfg_combine(noise_pred, uncond, cond, 5.0)
-        latent = sch.step(noise_pred.unsqueeze(0), ts_host[i], latent.unsqueeze(0), return_dict=False)[0].squeeze(0)
-
     def fence():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
-    fence()
     from wan.distributed.fsdp import BlockShards
     from wan.distributed.ulysses import HeadExchange
+
+    def measure(layout, is_primary):
+        """W warm-up steps + K timed steps of the loop body of wan/text2video.py:233-254 under one layout, its own model (same seed, same
+        weights), scheduler and latent.  -> dict"""
+        model = wan.modules.WanModel(**cfg, device=dev)
+        model.init_weights(seed=0)
+        model.eval().requires_grad_(False)
+        cfgp = None
+        if world > 1:
+            if layout == 'cfg':
+                from wan.distributed.cfg_parallel import enable_cfg_parallel
+                cfgp = enable_cfg_parallel(model)
+            else:
+                from wan.distributed.xdit_context_parallel import enable_sequence_parallel
+                enable_sequence_parallel(model)
+            if args.dit_fsdp:
+                from wan.distributed.fsdp import shard_model
+                shard_model(model, device_id=local)       # 1/N of every block's GEMM weights per rank, gathered one block ahead
+        sch = FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)
+        sch.set_timesteps(50, device=dev, shift=5.0)
+        ts = sch.timesteps
+        ts_host = ts.tolist()
+        st = {'latent': latent0.clone()}
+        noise_pred = torch.empty_like(latent0)
+
+        def step(i):
+            latent = st['latent']
+            t = ts[i:i + 1]
+            if cfgp is None:
+                cond = model([latent], t=t, context=[ctx], seq_len=L)[0]
+                uncond = model([latent], t=t, context=[ctx_null], seq_len=L)[0]
+            else:
+                mine = model([latent], t=t, context=[ctx_null if cfgp.branch else ctx], seq_len=L)[0]
+                cond, uncond = cfgp.exchange(mine)
+            ops.cfg_combine(noise_pred, uncond, cond, 5.0)
+            st['latent'] = sch.step(noise_pred.unsqueeze(0), ts_host[i], latent.unsqueeze(0), return_dict=False)[0].squeeze(0)
+
+        for i in range(args.warmup):
+            step(i)
+        fence()
+        if world > 1:
+            HeadExchange.trace = []          # events around every collective / every wait of the compute stream on one
+            if args.dit_fsdp:
+                BlockShards.trace = []
+        recording['on'] = is_primary
+        tel = _telemetry(local).start() if rank == 0 else None        # a thread reading sysfs through libamd_smi twice a second: nothing in the GPU's way
+        t0 = time.perf_counter()
+        for i in range(args.warmup, total):
+            step(i)
+        fence()
+        elapsed = time.perf_counter() - t0
+        R = {'layout': layout, 'model': model, 'cfgp': cfgp, 'sp': model.sp_size, 'telemetry': tel.stop() if tel is not None else None,
+             'overlap': None, 'fsdp_trace': None, 'sp_groups': None, 'peer_used': False}
+        recording['on'] = False
+        if world > 1:
+            tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = tt.item()
+            R['overlap'] = HeadExchange.overlap_summary()
+            HeadExchange.trace = None
+            R['peer_used'] = any('xchg' in w_ and w_['xchg'].peer is not None for w_ in model._ws.values())
+            xchgs = [w_['xchg'] for w_ in model._ws.values() if 'xchg' in w_]
+            R['sp_groups'] = {'heads_per_group': [n for _, n in xchgs[0].groups], 'attention_rounds_per_layer': xchgs[0].rounds,
+                              'chosen_by': os.environ.get('MOVIIGEN_SP_GROUPS', '') or 'auto'} if xchgs else None
+            if args.dit_fsdp:
+                from wan.distributed.collectives import trace_summary
+                R['fsdp_trace'] = trace_summary(BlockShards.trace)
+                BlockShards.trace = None
+        R['elapsed'] = elapsed
+        R['latent'] = st['latent']
+        assert torch.isfinite(R['latent']).all().item(), 'non-finite latent'
+        R['parallelism'] = ('single' if world == 1 else f'cfg2 x ulysses_sp{R["sp"]}' if cfgp is not None else f'ulysses_sp{R["sp"]}') + \
+                           (f' x fsdp{world}' if args.dit_fsdp and world > 1 else '')
+        return R
+
+    R = measure(primary, True)
+    other = None
+    if secondary is not None:
+        # the second layout of the same video on the same ranks, its own warm-up and K timed steps; the primary's model is released first
+        lat_primary = R['latent']
+        R['model']._ws = {}
+        R['model'] = None
+        torch.cuda.empty_cache()
+        R2 = measure(secondary, False)
+        per = 1.0 / args.steps
+        other = {'parallelism': R2['parallelism'], 'value': args.steps / R2['elapsed'], 'ms_per_step': R2['elapsed'] / args.steps * 1e3,
+                 'latent_max_abs_diff_vs_primary': (R2['latent'] - lat_primary).abs().max().item(),
+                 'overlap': ({'groups': R2['sp_groups'], 'exchange_ms_per_step': R2['overlap']['exchange_ms'] * per,
+                              'exposed_ms_per_step': R2['overlap']['exposed_ms'] * per, 'hidden_frac': R2['overlap']['hidden_frac']}
+                             if R2['overlap'] and R2['overlap']['collectives'] else None),
+                 'note': 'same run, same ranks, same video, same K / W: the other layout of the N > 1 forward (both compute the same step; '
+                         'latent_max_abs_diff_vs_primary is what the different summation order of the all-gathered rows leaves: 0)'}
+        model, cfgp = R2['model'], R2['cfgp']
+    else:
+        model, cfgp = R['model'], R['cfgp']
+    sp, elapsed, telemetry, latent = R['sp'], R['elapsed'], R['telemetry'], R['latent']
+    overlap, fsdp_trace, sp_groups, peer_used = R['overlap'], R['fsdp_trace'], R['sp_groups'], R['peer_used']
+    rank_devices = None
     if world > 1:
-        HeadExchange.trace = []          # events around every collective / every wait of the compute stream on one
-        if args.dit_fsdp:
-            BlockShards.trace = []
-    recording['on'] = True
-    tel = _telemetry(local).start() if rank == 0 else None        # a thread reading sysfs through libamd_smi twice a second: nothing in the GPU's way
-    t0 = time.perf_counter()
-    for i in range(args.warmup, total):
-        step(i)
-    fence()
-    elapsed = time.perf_counter() - t0
-    telemetry = tel.stop() if tel is not None else None
-    recording['on'] = False
-    overlap = rank_devices = fsdp_trace = sp_groups = None
-    peer_used = False
-    if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = tt.item()
-        overlap = HeadExchange.overlap_summary()
-        HeadExchange.trace = None
-        peer_used = any('xchg' in w_ and w_['xchg'].peer is not None for w_ in model._ws.values())
-        xchgs = [w_['xchg'] for w_ in model._ws.values() if 'xchg' in w_]
-        sp_groups = {'heads_per_group': [n for _, n in xchgs[0].groups], 'attention_rounds_per_layer': xchgs[0].rounds,
-                     'chosen_by': os.environ.get('MOVIIGEN_SP_GROUPS', 'auto')} if xchgs else None
-        if args.dit_fsdp:
-            from wan.distributed.collectives import trace_summary
-            fsdp_trace = trace_summary(BlockShards.trace)
-            BlockShards.trace = None
         mine = {'rank': rank, 'device': f'cuda:{local}', 'name': torch.cuda.get_device_name(dev),
                 'uuid': str(getattr(torch.cuda.get_device_properties(dev), 'uuid', ''))}
         rank_devices = [None] * world
         dist.all_gather_object(rank_devices, mine)
-    assert torch.isfinite(latent).all().item(), 'non-finite latent'
 
     # ---- the rest of sec/video (reference wan/text2video.py:228-261), measured in this same process after the timed
     # region: WanVAE.decode of a latent of this size on rank 0 (the reference decodes on rank 0 only) and, reported
@@ -554,8 +623,7 @@ def main():
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_step, 'higher_is_better': True,
             'scaling': 'strong', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
             'config': {'workload': desc, 'latent': list(lat_shape), 'tokens': L, 'layers': cfg['num_layers'],
-                       'parallelism': ('single' if world == 1 else f'cfg2 x ulysses_sp{sp}' if cfgp is not None else f'ulysses_sp{sp}')
-                                      + (f' x fsdp{world}' if args.dit_fsdp and world > 1 else ''), 'solver': 'unipc',
+                       'parallelism': R['parallelism'], 'solver': 'unipc',
                        'guide_scale': 5.0, 'weights': 'random N(0,0.02) bf16, seed 0',
                        **({'gemm_variant': args.gemm_variant} if args.gemm_variant else {})},
             'sec_per_video': (ms_step * 50 / 1e3 + vae_s) if vae_s is not None else None,
@@ -612,10 +680,19 @@ def main():
             from wan.distributed import rccl_direct
             gloo = os.environ.get('MOVIIGEN_BENCH_BACKEND') == 'gloo'
             line['rccl_ranks'] = 0 if gloo else world
+            if other is not None:
+                line['other_layout'] = other
+            if pre is not None:
+                from wan.distributed import preflight
+                line['preflight'] = {**preflight.parse(pre), 'peer_access': pre.get('peer_access'), 'stages_skipped': pre.get('stages_skipped'),
+                                     'how': 'wan/distributed/preflight.py before the warm-up: backend / ranks, hipDeviceCanAccessPeer per peer, a '
+                                            f'{pre.get("probe_bytes", 0) >> 20} MiB all-to-all on the exchange\'s default transport (GB/s a rank sends to the others, slowest '
+                                            'rank), and — only when the copy-engine transport is asked for — IPC windows + self-check + the same exchange as peer copies'}
+                line['link_gbps_measured'] = line['preflight']['link_gbps_measured']
             line['rank_devices'] = rank_devices
             # what the exchange objects REALLY use (a peer-copy request falls back to the collective when the IPC mapping fails)
             line['transport'] = {
-                'requested': args.transport or os.environ.get('MOVIIGEN_SP_TRANSPORT') or 'auto',
+                'requested': args.transport or os.environ.get('MOVIIGEN_SP_TRANSPORT') or 'torch',
                 'used': ('gloo through host memory (test plumbing)' if gloo else
                          'one-sided peer copies (hipMemcpyAsync D2D into IPC-mapped receive buffers) between two flag all-reduces' if peer_used else
                          "C-ABI collectives on the library's RCCL communicator (mg_sp_all_to_all: grouped ncclSend/ncclRecv)"

@@ -163,6 +163,7 @@ extern "C" int mg_gemm_set_variant(int v) {      // 110 + f / 200 + f: variant 1
     const int base = v >= 200 ? 12 : v >= 110 ? 11 : v;
     if (base != 0 && base != 1 && base != 2 && base != 7 && base != 8 && base != 11 && base != 12) return MG_ERR_ARG;      // no silent aliases
     if ((v >= 110 && v - 110 >= 64 && v < 200) || v >= 200 + 8192) return MG_ERR_ARG;
+    if (v >= 200 && (((v - 200) >> 5) & 3) == 2) return MG_ERR_ARG;      // variant 12: generated bodies 0 (bits 5-6 = 0 / 1) and 2 (= 3) are compiled; 264 + f named body 1, which is not
     g_gemm_variant = base;
     mg_gemm_v11_set_flags(v >= 110 && v < 200 ? v - 110 : 0);
     mg_gemm_v12_set_flags(v >= 200 ? v - 200 : 0);

@@ -102,10 +102,13 @@ __global__ __launch_bounds__(V11_THREADS, 1) void gemm_bf16_v12_kernel(
     int pos = raster ? 0 : bid >> 3;
     if (raster ? p256 >= total : pos >= xcd_count) return;
 #ifdef MG_AB_BUILD
-    // measurement (flags 2048 / 4096): XCD x starts x * 4 us / x * 16 us late — does a launch whose 256 workgroups begin their MFMA streams in the same
-    // microsecond pay for it with a clock dip?
+    // measurement (flags 2048 / 4096): the workgroups of an XCD start their tile streams SPREAD OVER TIME — slot s of the XCD (0..31) s x 4 us late
+    // (2048: 32 phases over ~one N = 5120 tile), or (s & 15) x 4 us (4096: 16 phases over half a tile).  All workgroups of a launch run the same
+    // tiles in lock-step, so the 32 CUs of an XCD reach their epilogues in the same microseconds and queue at the XCD's fabric port (32 x 512 KiB of
+    // fp32 read-modify-write per gated-residual tile); round 5's stagger delayed whole XCDs against each other, which leaves that queue as it is
+    // (profiles/r05y5_gemm_stagger.log: no effect).
     if (flags & (2048 | 4096)) {
-        const int units = xcd * ((flags & 4096) ? 4 : 1);
+        const int units = (flags & 4096) ? (slot & 15) : slot;
         for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(127);      // 127 x 64 cycles ~ 4 us
     }
 #endif
@@ -345,7 +348,7 @@ int mg_gemm_v2_launch(const uint16_t* A, int64_t lda, const uint16_t* Wt, int64_
                       int epilogue, void* out, int64_t ldo, const float* gate, hipStream_t st);      // gemm_bf16_v2.hip
 
 #ifdef MG_AB_BUILD
-static int g_v12_flags = 0;     // measurement bits (mg_gemm_set_variant(200 + flags)): 1 = fp32 outputs: residual batches not pipelined, 2 = raster 0 always, 4 = no stores (timing only), 8 = touch loads in front of the gated-residual epilogue, 128 = fp32 outputs: no residual loads (timing only), 256 / 512 = fp32 outputs: no nt hint on the stores / the residual loads, 1024 = bf16 outputs: no nt hint on the stores, 2048 / 4096 = XCD x starts 4 x / 16 x us late, 16 = fp32 outputs: direct epilogue, 32 * (1 + s) = generated body s (0 / 2)
+static int g_v12_flags = 0;     // measurement bits (mg_gemm_set_variant(200 + flags)): 1 = fp32 outputs: residual batches not pipelined, 2 = raster 0 always, 4 = no stores (timing only), 8 = touch loads in front of the gated-residual epilogue, 128 = fp32 outputs: no residual loads (timing only), 256 / 512 = fp32 outputs: no nt hint on the stores / the residual loads, 1024 = bf16 outputs: no nt hint on the stores, 2048 / 4096 = the XCD's workgroups start 4 us apart in 32 / 16 phases, 16 = fp32 outputs: direct epilogue, 32 * (1 + s) = generated body s (0 / 2)
 void mg_gemm_v12_set_flags(int f) { g_v12_flags = f; }
 #else
 static constexpr int g_v12_flags = 0;

@@ -65,6 +65,18 @@ struct Dev {
     Dev& operator=(const Dev&) = delete;
 };
 
+// the caller-owned ticket workspace of mg_attn_fwd_bf16_hd128* (include/moviigen_hip.h): this client allocates and zeroes it ONCE, outside
+// any launch; every launch of the (single) stream shares it
+static void* attn_ws() {
+    static void* ws = nullptr;
+    if (!ws) {
+        CK(hipMalloc(&ws, (size_t)mg_attn_workspace_bytes()));
+        CK(hipMemset(ws, 0, (size_t)mg_attn_workspace_bytes()));
+        CK(hipDeviceSynchronize());
+    }
+    return ws;
+}
+
 static int n_fail = 0;
 static void report(const char* name, double err, double tol) {
     const bool ok = (err <= tol) && !isnan(err);
@@ -337,8 +349,8 @@ static void test_attn(int64_t Lq, int64_t Lk, int heads, int nsamp, bool timeit,
         new (&dqs) Dev<uint16_t>(qs);
     }
     auto run = [&]() {
-        return prescaled ? mg_attn_fwd_bf16_hd128_prescaled(dqs.p, ld, dkp.p, dvp.p, dout.p, ld, nullptr, Lq, Lk, heads, 0, 0)
-                         : mg_attn_fwd_bf16_hd128(dq.p, ld, dkp.p, dvp.p, dout.p, ld, Lq, Lk, heads, scale, 0);
+        return prescaled ? mg_attn_fwd_bf16_hd128_prescaled(dqs.p, ld, dkp.p, dvp.p, dout.p, ld, nullptr, Lq, Lk, heads, 0, attn_ws(), 0)
+                         : mg_attn_fwd_bf16_hd128(dq.p, ld, dkp.p, dvp.p, dout.p, ld, Lq, Lk, heads, scale, attn_ws(), 0);
     };
     rc |= run();
     CK(hipDeviceSynchronize());
@@ -472,8 +484,8 @@ static void attn_ab(int64_t L, int heads, int data, const std::vector<int>& vari
             cnt.zero();
             CK(hipMemset(dout.p, 0xff, dout.n * 2));
             auto run = [&]() {
-                return var >= 10 ? mg_attn_fwd_bf16_hd128_prescaled(dqs.p, ld, dkp.p, dvp.p, dout.p, ld, nullptr, L, L, heads, reserve, 0)
-                                 : mg_attn_fwd_bf16_hd128(dq.p, ld, dkp.p, dvp.p, dout.p, ld, L, L, heads, scale, 0);
+                return var >= 10 ? mg_attn_fwd_bf16_hd128_prescaled(dqs.p, ld, dkp.p, dvp.p, dout.p, ld, nullptr, L, L, heads, reserve, attn_ws(), 0)
+                                 : mg_attn_fwd_bf16_hd128(dq.p, ld, dkp.p, dvp.p, dout.p, ld, L, L, heads, scale, attn_ws(), 0);
             };
             rc |= run();
             CK(hipDeviceSynchronize());
@@ -709,7 +721,7 @@ int main(int argc, char** argv) {
         CK(hipMemset(dkp.p, 0x3c, dkp.n * 2));
         CK(hipMemset(dvp.p, 0x3c, dvp.n * 2));
         int rc = 0;
-        for (int i = 0; i < 2; ++i) rc |= mg_attn_fwd_bf16_hd128_prescaled(dq.p, ld, dkp.p, dvp.p, dout.p, ld, nullptr, L, L, heads, 0, 0);
+        for (int i = 0; i < 2; ++i) rc |= mg_attn_fwd_bf16_hd128_prescaled(dq.p, ld, dkp.p, dvp.p, dout.p, ld, nullptr, L, L, heads, 0, attn_ws(), 0);
         CK(hipDeviceSynchronize());
         printf("attnpmc L=%lld heads=%d rc=%d\n", (long long)L, heads, rc);
         return rc ? 1 : 0;
@@ -761,7 +773,7 @@ int main(int argc, char** argv) {
             Dev<uint16_t> dq((size_t)M * ld), dkp((size_t)npk), dvp((size_t)npk), dout((size_t)M * ld);
             fill(dq.p, dq.n); fill(dkp.p, dkp.n); fill(dvp.p, dvp.n);
             while (ms_sum < secs * 1e3) {
-                ms_sum += 4 * time_ms([&] { mg_attn_fwd_bf16_hd128_prescaled(dq.p, ld, dkp.p, dvp.p, dout.p, ld, nullptr, M, M, heads, 0, 0); }, 4);
+                ms_sum += 4 * time_ms([&] { mg_attn_fwd_bf16_hd128_prescaled(dq.p, ld, dkp.p, dvp.p, dout.p, ld, nullptr, M, M, heads, 0, attn_ws(), 0); }, 4);
                 launches += 4;
             }
             printf("powerloop attention: %ld launches, %.3f ms each = %.1f TFLOP/s\n", launches, ms_sum / launches,

@@ -99,3 +99,26 @@ def rendezvous(flag, group):
     if _test_transport.staged(flag, group):
         return _test_transport.rendezvous(group)
     dist.all_reduce(flag, group=group)
+
+
+# ---- control plane: scalars, not tensors of the path ---------------------------------------------------------------------------------
+def _on_host(group):
+    """gloo moves host memory only (the CPU tests and the ranks-sharing-one-GPU tests); RCCL moves device memory."""
+    return dist.get_backend(group) == 'gloo'
+
+
+def control_reduce(value, op, group, device, dtype=torch.float64):
+    """one python number reduced over the group ('min' / 'max' / 'sum') -> python number, the same on every rank.  Host round trip: for votes,
+    clocks and flags around the path (fallback decisions, preflight timings) — never inside a layer."""
+    group = group if group is not None else dist.group.WORLD
+    t = torch.tensor([value], dtype=dtype, device='cpu' if _on_host(group) else device)
+    dist.all_reduce(t, op={'min': dist.ReduceOp.MIN, 'max': dist.ReduceOp.MAX, 'sum': dist.ReduceOp.SUM}[op], group=group)
+    return t.item()
+
+
+def control_broadcast(value, src, group, device, dtype=torch.float64):
+    """group rank `src`'s python number -> every rank."""
+    group = group if group is not None else dist.group.WORLD
+    t = torch.tensor([value], dtype=dtype, device='cpu' if _on_host(group) else device)
+    dist.broadcast(t, src=src if group is dist.group.WORLD else dist.get_global_rank(group, src), group=group)
+    return t.item()

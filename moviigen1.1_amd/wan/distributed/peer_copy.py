@@ -27,8 +27,11 @@ from . import collectives
 
 
 def mode():
-    """MOVIIGEN_SP_TRANSPORT: 'auto' (default) | 'peer_copy' | 'torch' | 'rccl_direct'"""
-    return os.environ.get('MOVIIGEN_SP_TRANSPORT', '') or 'auto'
+    """MOVIIGEN_SP_TRANSPORT: 'torch' (default: the all-to-all collective) | 'auto' | 'peer_copy' | 'rccl_direct'.
+    The copy-engine transport is OPT-IN: it has run on gloo ranks sharing one GPU and on RCCL at world size 1 only — until a
+    multi-GPU run has shown it correct and faster (`bench.py --preflight` measures both transports before the warm-up, tools/scale_sweep.sh
+    runs both), a real multi-GPU launch stays on the collective unless `auto` / `peer_copy` is asked for by name."""
+    return os.environ.get('MOVIIGEN_SP_TRANSPORT', '') or 'torch'
 
 
 def enabled():
@@ -36,8 +39,8 @@ def enabled():
 
 
 def wanted(group, device):
-    """does a HeadExchange on `group` try the copy-engine transport?  Always when it is asked for by name; in `auto` mode when the group
-    runs on RCCL with more than one rank on device buffers — i.e. on a real multi-GPU launch: the copy engines move the bytes there and the
+    """does a HeadExchange on `group` try the copy-engine transport?  When it is asked for by name; in `auto` mode when the group runs on
+    RCCL with more than one rank on device buffers — i.e. on a real multi-GPU launch: the copy engines move the bytes there and the
     persistent attention grid keeps every CU (a kernel transport only runs once an attention launch has ended).  A window that
     cannot be opened on every rank, or that fails its self-check, leaves the exchange on the collective (logged, `transport.used` says so)."""
     if torch.device(device).type != 'cuda' or group is None:
@@ -52,32 +55,59 @@ def wanted(group, device):
         return False
 
 
-def self_check(win, group, buffer_index=0):
-    """ONE exchange of a known pattern through the windows, before the first real one: chunk p of rank r's send image carries the value
-    1000 r + p, so slot s of MY buffer must read 1000 s + my rank.  All ranks or none: a mismatch anywhere (a mapping that opened but does
-    not reach the right memory) sends the whole group back to the collective.  -> win or None"""
+PROBE_ELEMS = 4096      # elements of every slot the self-check writes (and restores)
+
+
+def _vote(ok, group, device):
+    """MIN over the group of a 0/1 flag: all ranks or none.  Every rank reaches this, whatever happened before."""
+    return int(collectives.control_reduce(int(ok), 'min', group, device, dtype=torch.int32)) == 1
+
+
+def self_check(win, group, buffer_indices=None):
+    """ONE small pattern exchange through the windows before the first real one, on the first buffer of each half of the list (a q|k|v
+    receive buffer and a return buffer): rank r writes the value (7 r + p) % 251 (exact in bf16) into the first PROBE_ELEMS elements of
+    slot [r] of rank p's buffer, so slot s of MY buffer must read (7 s + my rank) % 251.  All ranks or none: a mismatch or ANY exception
+    anywhere (a mapping that opened but does not reach the right memory, a copy the runtime refuses, an allocation that fails) sends the
+    whole group back to the collective — nothing here can raise past the vote, so no rank is left waiting in it.  The probe touches
+    P x PROBE_ELEMS elements per buffer and restores them; no full-size temporaries.  -> win or None"""
     import logging
-    buf = win.local[buffer_index]
-    P, r = win.P, win.rank
-    keep = buf.clone()
-    send = torch.empty((P,) + tuple(buf.view(P, -1).shape[1:]), dtype=buf.dtype, device=buf.device)
-    for p in range(P):
-        send[p].fill_(float((7 * r + p) % 251))          # exact in bf16
-    res = win.all_to_all(buffer_index, send, probe=True)
-    got = buf.view(P, -1)
-    want = torch.tensor([float((7 * s_ + r) % 251) for s_ in range(P)], dtype=torch.float32, device=buf.device)
-    if isinstance(res, Exception):
-        logging.warning(f'peer-copy transport: a copy of the self-check was refused on rank {r} ({type(res).__name__}: {res})')
+    ok = 1
+    try:
+        P, r = win.P, win.rank
+        if buffer_indices is None:
+            buffer_indices = sorted({0, len(win.local) // 2})
+        for bi in buffer_indices:
+            mine = win.local[bi].view(P, -1)
+            n = min(PROBE_ELEMS, mine.shape[1])
+            keep = mine[:, :n].clone()
+            win._rendezvous()                                    # every rank saved its slots
+            error = None
+            try:
+                for k in range(P):
+                    p = (r + k) % P
+                    src = torch.full((n,), float((7 * r + p) % 251), dtype=mine.dtype, device=mine.device)
+                    win.views[bi][p].view(P, -1)[r, :n].copy_(src, non_blocking=True)
+            except Exception as e:      # noqa: BLE001 — refused here: the peers must still find this rank in the rendezvous
+                error = e
+            win._rendezvous()                                    # all writes have landed everywhere
+            if error is not None:
+                logging.warning(f'peer-copy transport: a copy of the self-check was refused on rank {r} ({type(error).__name__}: {error})')
+                ok = 0
+            else:
+                for s_ in range(P):                              # per slot, in the buffer's own dtype
+                    val = torch.tensor(float((7 * s_ + r) % 251), dtype=mine.dtype, device=mine.device)
+                    if not bool((mine[s_, :n] == val).all()):
+                        ok = 0
+            mine[:, :n].copy_(keep)
+    except Exception as e:      # noqa: BLE001
+        logging.warning(f'peer-copy transport: the self-check failed on rank {getattr(win, "rank", "?")} ({type(e).__name__}: {e})')
         ok = 0
-    else:
-        ok = int(torch.equal(got.float(), want[:, None].expand_as(got)))
-    buf.copy_(keep)
-    flag = torch.tensor([ok], dtype=torch.int32, device=buf.device)
-    g = win.group
-    if dist.get_backend(g) == 'gloo':
-        flag = flag.cpu()
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=g)
-    if int(flag.item()) != 1:
+    try:
+        agreed = _vote(ok, win.group, win.local[0].device)
+    except Exception as e:      # noqa: BLE001 — the control plane itself failed: nothing to fall back with, but say what happened
+        logging.warning(f'peer-copy transport: the fallback vote failed ({type(e).__name__}: {e})')
+        raise
+    if not agreed:
         logging.warning('peer-copy transport: the self-check exchange did not arrive intact on every rank; falling back to the all-to-all collective')
         return None
     return win
@@ -96,12 +126,8 @@ def open_windows(group, buffers):
         logging.warning(f'MOVIIGEN_SP_TRANSPORT=peer_copy: mapping the peers\' receive buffers failed ({type(e).__name__}: {e}); '
                         'falling back to the all-to-all collective')
         win, ok = None, 0
-    flag = torch.tensor([ok], dtype=torch.int32, device=buffers[0].device)
     g = group if group is not None else dist.group.WORLD
-    if dist.get_backend(g) == 'gloo':
-        flag = flag.cpu()
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=g)           # all ranks or none
-    if int(flag.item()) != 1:
+    if not _vote(ok, g, buffers[0].device):                         # all ranks or none
         return None
     return self_check(win, g)
 
@@ -141,22 +167,31 @@ class PeerWindows:
     def _rendezvous(self):
         collectives.rendezvous(self.flag, self.group)           # 4-byte all-reduce enqueued on the current (communication) stream
 
-    def all_to_all(self, i, send, probe=False):
+    def all_to_all(self, i, send):
         """buffer i of every rank <- the P chunks of `send` ([P, ...], chunk p goes to rank p), all_to_all_single layout:
-        slot [source rank] of the destination's buffer.  probe (the self-check): a copy the runtime refuses on THIS rank must not leave the
-        peers waiting in the second rendezvous — it is caught, the rendezvous still happens, and the error is returned instead of the buffer."""
+        slot [source rank] of the destination's buffer.  A copy the runtime refuses on THIS rank must not leave the peers waiting in the
+        second rendezvous: it is caught, 1 is added to this rank's flag word — the rendezvous all-reduces (sums) that word, so from then on
+        it is non-zero on EVERY rank — and the rendezvous still happens.  `failed()` reads the word; the caller (HeadExchange.peer_failed,
+        once per forward) then takes the whole group back to the collective and repeats the forward."""
         P, r = self.P, self.rank
         assert send.shape[0] == P and send.is_contiguous()
         self._rendezvous()
-        error = None
         try:
             for k in range(P):
                 p = (r + k) % P                                  # start with the local copy, then walk the ring: no hot peer
                 dst = self.views[i][p].view(P, *send.shape[1:])[r]
                 dst.copy_(send[p], non_blocking=True)            # contiguous, same dtype: one hipMemcpyAsync D2D (peer)
         except Exception as e:      # noqa: BLE001
-            if not probe:
-                raise
-            error = e
+            import logging
+            logging.warning(f'peer-copy transport: a copy was refused on rank {r} ({type(e).__name__}: {e}); the group will fall back to the collective')
+            self.flag.add_(1)
         self._rendezvous()
-        return error if probe and error is not None else self.local[i]
+        return self.local[i]
+
+    def failed(self):
+        """has any rank's copy failed since the windows were opened?  (one 4-byte read: a host sync — call it once per forward, not per
+        exchange.)  The word only ever changes through the rendezvous all-reduce, so every rank reads the same answer after the same exchange."""
+        word = int(self.flag.item())
+        if collectives._test_transport.staged(self.flag, self.group):     # the one-GPU test transport's rendezvous is a host barrier: the word is local
+            word = int(collectives.control_reduce(word, 'max', self.group, self.flag.device, dtype=torch.int32))
+        return word != 0

@@ -116,15 +116,19 @@ class HeadExchange:
         self.group, self.P, self.hd, self.Lloc = group, P, head_dim, Lloc
         self.n_loc = heads // P
         self.cols = self.n_loc * head_dim                      # columns of one destination's head slice
+        # the CUs an attention launch of this exchange really gets: the device's, minus what MOVIIGEN_SP_RESERVE_CUS leaves to a collective
+        # kernel (only honoured on a kernel transport with >= 2 groups, see reserve_cus below) — the group choice and the reported round
+        # count are made for THAT grid
+        n_cu = torch.cuda.get_device_properties(device).multi_processor_count if torch.device(device).type == 'cuda' else 256
+        want_reserve = 0 if peer_copy.wanted(group, device) else (int(os.environ.get('MOVIIGEN_SP_RESERVE_CUS', '0') or 0) + 7) & ~7
+        n_cu_attn = max(8, (n_cu & ~7) - want_reserve)
         if max_groups is None:
-            env = os.environ.get('MOVIIGEN_SP_GROUPS', 'auto')
+            env = os.environ.get('MOVIIGEN_SP_GROUPS', '') or 'auto'      # an empty value means auto
             if env == 'auto':                                  # by shape: rounds of the persistent attention grid vs exposed exchange
-                n_cu = torch.cuda.get_device_properties(device).multi_processor_count if torch.device(device).type == 'cuda' else 256
-                max_groups = choose_groups(self.n_loc, P * Lloc, P, dim=heads * head_dim, n_cu=n_cu)[0] if head_dim == 128 else min(5, self.n_loc)
+                max_groups = choose_groups(self.n_loc, P * Lloc, P, dim=heads * head_dim, n_cu=n_cu_attn)[0] if head_dim == 128 else min(5, self.n_loc)
             else:
                 max_groups = int(env)
         self.groups = split_heads(self.n_loc, max_groups)
-        self.rounds = sum(attention_rounds(n, P * Lloc) for _, n in self.groups)
         bf = torch.bfloat16
         e = lambda *s: torch.empty(*s, dtype=bf, device=device)  # noqa: E731
         self.send, self.recv, self.ag, self.orecv = [], [], [], []
@@ -134,7 +138,7 @@ class HeadExchange:
             self.recv.append(e(P * Lloc, 3 * w))
             self.ag.append(e(P * Lloc, w))
             self.orecv.append(e(P, Lloc, w))
-        # The copy-engine transport (MOVIIGEN_SP_TRANSPORT=auto, the default, on an RCCL group of more than one rank; or =peer_copy): the
+        # The copy-engine transport (opt-in: MOVIIGEN_SP_TRANSPORT=auto on an RCCL group of more than one rank, or =peer_copy): the
         # receive buffers are mapped into the peers once, checked with one pattern exchange, and an exchange is then P one-sided device
         # copies on the comm stream (copy engines, no CUs) between two 4-byte rendezvous
         self.peer = None
@@ -147,9 +151,21 @@ class HeadExchange:
         # configs[2] group size (profiles/r04b_sp_overlap.txt): leaving 8 CUs free costs MORE than the exposed
         # exchange it could hide (512 query blocks of a one-head group on 248 instead of 256 workgroups = three rounds
         # instead of two: +28 % attention time) — the default is 0; the copy-engine transport needs none either way.
-        self.reserve_cus = 0 if self.peer is not None or len(self.groups) < 2 else int(os.environ.get('MOVIIGEN_SP_RESERVE_CUS', '0'))
+        self.reserve_cus = 0 if self.peer is not None or len(self.groups) < 2 else int(os.environ.get('MOVIIGEN_SP_RESERVE_CUS', '0') or 0)
+        self.rounds = sum(attention_rounds(n, P * Lloc, (n_cu & ~7) - ((self.reserve_cus + 7) & ~7)) for _, n in self.groups)
         ev = lambda: [torch.cuda.Event() for _ in self.groups]  # noqa: E731
         self.ev_pack, self.ev_recv, self.ev_attn, self.ev_o = ev(), ev(), ev(), ev()
+
+    def peer_failed(self):
+        return self.peer is not None and self.peer.failed()
+
+    def drop_peer(self):
+        """back to the all-to-all collective for good (a copy of the copy-engine transport failed somewhere in the group)."""
+        import logging
+        if self.peer is not None:
+            logging.warning('Ulysses exchange: the peer-copy transport reported a failed copy; this exchange now uses the all-to-all collective')
+        self.peer = None
+        self.reserve_cus = 0 if len(self.groups) < 2 else int(os.environ.get('MOVIIGEN_SP_RESERVE_CUS', '0') or 0)
 
     def run(self, q, k, v, out, attend):
         """q, k, v: [Lloc, heads*hd] bf16 (column slices of the fused qkv buffer are fine); out [Lloc, heads*hd].

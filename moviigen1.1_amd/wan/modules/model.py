@@ -656,8 +656,25 @@ class WanModel(nn.Module):
         if clip_fea is not None or y is not None:
             raise NotImplementedError('image conditioning (i2v) is not part of MoviiGen1.1 T2V')
         t = t.reshape(-1)
-        return [self._forward_one(u, t[i if t.numel() > 1 else 0], c, seq_len)
+        outs = [self._forward_one(u, t[i if t.numel() > 1 else 0], c, seq_len)
                 for i, (u, c) in enumerate(zip(x, context))]
+        if self._peer_transport_failed():
+            # a copy of the copy-engine transport was refused on some rank during this forward (every rank reads the same answer): the
+            # whole group goes back to the all-to-all collective, for good, and the forward is repeated on it
+            outs = [self._forward_one(u, t[i if t.numel() > 1 else 0], c, seq_len)
+                    for i, (u, c) in enumerate(zip(x, context))]
+        return outs
+
+    def _peer_transport_failed(self):
+        """once per forward (one 4-byte read per open window set — nothing at all on the default collective transport): did a peer copy
+        fail?  If so every HeadExchange of this model drops its windows (wan/distributed/peer_copy.py)."""
+        xs = [w['xchg'] for w in self._ws.values() if 'xchg' in w]
+        xs = [x for x in xs if x.peer is not None]
+        if not xs or not any(x.peer_failed() for x in xs):
+            return False
+        for x in xs:
+            x.drop_peer()
+        return True
 
     def unpatchify(self, x, grid_sizes):
         outs = []

@@ -94,6 +94,24 @@ for depth in ('1', '2', '5', None):      # forced pipeline depths, then the shap
         else:
             want = min(heads // m.sp_size, int(depth))
         assert len(x.groups) == want, (x.groups, want)
+if os.environ.get('MOVIIGEN_SP_TRANSPORT') == 'peer_copy' and cp is None and m.sp_size > 1:
+    # hard fallback AFTER the windows are open: ONE rank's runtime refuses a peer copy in the middle of a forward.
+    # Nobody may hang in a rendezvous; every rank must learn of it, drop its windows, repeat the forward on the all-to-all collective
+    # and return the right bits.
+    x = m._ws[next(iter(m._ws))]['xchg']
+    assert x.peer is not None
+
+    class Refused:
+        def view(self, *a):
+            raise RuntimeError('injected fault: peer copy refused')
+    if rank == world - 1:
+        x.peer.views[0][0] = Refused()                       # rank 0's first receive buffer as mapped HERE
+    c = m([lat], t=ts[0], context=[ctx], seq_len=L)[0].clone()
+    assert torch.equal(c, refs[0][0]), (c - refs[0][0]).abs().max().item()
+    assert x.peer is None and not m._peer_transport_failed()
+    u = m([lat], t=ts[0], context=[ctx_null], seq_len=L)[0]
+    assert torch.equal(u, refs[0][1])
+    print(f'PEER_FALLBACK_OK rank{rank}/{world}', flush=True)
 torch.cuda.synchronize()
 print(f'HYBRID_OK {mode} {backend} rank{rank}/{world}', flush=True)
 dist.barrier()

@@ -359,6 +359,37 @@ def test_attention_items_by_ticket(dev):
     torch.cuda.synchronize()
     for o in outs:
         assert torch.equal(o, static)
+    # ABI 9: the pair lives in a CALLER-owned workspace (mg_attn_workspace_bytes() zeroed bytes); the library allocates nothing and
+    # synchronises nothing on a launch path.  A launch leaves the workspace zeroed; NULL = the static partition.
+    nbytes = int(lib.load().mg_attn_workspace_bytes())
+    assert 8 <= nbytes <= 4096
+    for st in [torch.cuda.current_stream()] + streams:
+        assert int(ops.attention_workspace(dev, st).count_nonzero()) == 0
+    assert torch.equal(run(workspace=None), static)
+    mine = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+    o = torch.zeros(L, N * 128, dtype=torch.bfloat16, device=dev)
+    fresh = torch.cuda.Stream(device=dev)                  # a stream no TICKETED launch has run on (the runtime's own first-use
+    with torch.cuda.stream(fresh):                         # allocations of a new stream — queue, signals, kernel-argument pool — are
+        ops.attention_hd128(q[:256], kp, vp, o[:256], L, 4, 1.0, prescaled=True, workspace=None)   # made by this plain launch)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(dev)[0]                # hipMemGetInfo
+    with torch.cuda.stream(fresh):
+        ops.attention_hd128(q, kp, vp, o, L, N, 1.0, prescaled=True, workspace=mine)
+    free1 = torch.cuda.mem_get_info(dev)[0]
+    torch.cuda.synchronize()
+    assert free1 == free0 and torch.equal(o, static) and int(mine.count_nonzero()) == 0
+    # ... and the FIRST ticketed launch of a process/stream is capturable: capture it, replay it twice
+    o.zero_()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        ops.attention_hd128(q, kp, vp, o, L, N, 1.0, prescaled=True, workspace=mine)
+    for _ in range(2):
+        o.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(o, static) and int(mine.count_nonzero()) == 0
+    with pytest.raises(lib.MoviigenHipError):              # a misaligned workspace is refused, not used
+        ops.attention_hd128(q, kp, vp, o, L, N, 1.0, prescaled=True, workspace=mine[4:])
 
 
 @pytest.fixture(params=[0, 3], ids=['m16', 'w64'])
@@ -1403,6 +1434,8 @@ def _run_hybrid(world, backend, layout, port, transport='torch', model=None):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     for k in range(world):
         assert f'HYBRID_OK {layout} {backend} rank{k}/{world}' in r.stdout, r.stdout[-2000:]
+        if transport == 'peer_copy' and layout == 'sp_fsdp':      # the injected refused copy: every rank fell back and still got the right bits
+            assert f'PEER_FALLBACK_OK rank{k}/{world}' in r.stdout, r.stdout[-2000:]
 
 
 @pytest.mark.parametrize('world,layout', [(4, 'cfg_sp_fsdp'), (2, 'sp_fsdp'), (4, 'sp_fsdp')])
@@ -1630,9 +1663,9 @@ def test_attention_lse_and_merge(dev):
         ops.attention_hd128_lse(q, kp, vp, out, torch.empty(3, dtype=torch.float32, device=dev), Lk, heads, 1.0)
 
 
-@pytest.mark.parametrize('world,extra,plain', [(2, [], False), (4, [], True), (2, ['--no-cfg-parallel'], True),
+@pytest.mark.parametrize('world,extra,plain', [(2, ['--cfg-parallel'], False), (4, [], True), (2, ['--no-cfg-parallel', '--single-layout'], True),
                                                (4, ['--dit-fsdp', '--vae-parallel', '--transport', 'peer_copy', '--layers', '3'], False)],
-                         ids=['cfg2_torchrun', 'cfg2_sp2_plain', 'sp2_plain', 'configs3_form_cfg2_sp2_fsdp4_vaepipe_peercopy'])
+                         ids=['cfg2_primary_torchrun', 'sp4_and_cfg2_sp2_plain', 'sp2_single_layout_plain', 'configs3_form_cfg2_sp2_fsdp4_vaepipe_peercopy'])
 def test_bench_multirank_code_path(world, extra, plain):
     """bench.py's N > 1 branches (CFG-parallel halves x Ulysses, or Ulysses over all ranks; block-sharded weights,
     pipelined VAE tail, exchange transport) on one GPU through gloo, tiny workload: must print ONE JSON line with the
@@ -1659,13 +1692,27 @@ def test_bench_multirank_code_path(world, extra, plain):
               'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'sec_per_video', 'vae_decode'):
         assert k in d, k
     assert d['n_gpus'] == world and d['scaling'] == 'strong' and d['value'] > 0
-    want = f'ulysses_sp{world}' if '--no-cfg-parallel' in extra else (f'cfg2 x ulysses_sp{world // 2}')
+    # primary layout: Ulysses over all ranks (BASELINE configs[2], the reference's layout) unless --cfg-parallel / --dit-fsdp (configs[3]);
+    # the other layout of an even world is measured in the same run and reported beside it
     fsdp = '--dit-fsdp' in extra
+    cfg_first = '--cfg-parallel' in extra or fsdp
+    want = f'cfg2 x ulysses_sp{world // 2}' if cfg_first else f'ulysses_sp{world}'
     assert d['config']['parallelism'] == want + (f' x fsdp{world}' if fsdp else ''), d['config']
+    if fsdp or '--single-layout' in extra:
+        assert 'other_layout' not in d
+    else:
+        o = d['other_layout']
+        assert o['parallelism'] == (f'ulysses_sp{world}' if cfg_first else f'cfg2 x ulysses_sp{world // 2}') and o['value'] > 0
+        assert o['latent_max_abs_diff_vs_primary'] == 0.0          # both layouts computed the same K + W steps of the same video
+    # the preflight leg: backend / ranks / peer access / the 64 MiB all-to-all probe; the IPC probe only with the copy-engine transport
+    pf = d['preflight']
+    assert pf['rccl_ranks'] == 0 and pf['link_gbps_measured']['all_to_all'] > 0 and not pf['preflight_errors'], pf
+    assert pf['transport_recommended'] in ('torch', 'peer_copy') and len(pf['peer_access']) == world
+    assert (pf['ipc_open'] is True and pf['link_gbps_measured']['peer_copy'] > 0) == ('peer_copy' in extra), pf
     # what the line says about the ranks: gloo plumbing here (rccl_ranks 0), one entry per rank, overlap measured
     # whenever the layout has a per-layer exchange (cfg2 on 2 ranks has none)
     assert d['rccl_ranks'] == 0 and 'gloo' in d['transport']['used'] and len(d['rank_devices']) == world
-    assert d['transport']['requested'] == ('peer_copy' if 'peer_copy' in extra else 'auto')      # auto: the collective here (gloo group)
+    assert d['transport']['requested'] == ('peer_copy' if 'peer_copy' in extra else 'torch')     # the collective is the default
     if fsdp:
         f = d['fsdp']
         assert f['ranks'] == world and f['gathers_per_step'] >= 2 and f['gather_ms_per_step'] > 0 and 0 <= f['exposed_ms_per_step']

@@ -257,8 +257,10 @@ def write(name, sch, note):
 
 
 if __name__ == '__main__':
-    only = [int(a) for a in sys.argv[1:]]
+    # without arguments: the two bodies the library compiles (0 = shipped, 2 = its A/B partner); `... 1 3 4 5` regenerates the bodies
+    # that were measured and archived (experiments/gemm_v12_bodies/, set MG_V12_GEN_DIR to write there)
+    only = [int(a) for a in sys.argv[1:]] or [0, 2]
     for n, (note, ev) in SCHEDULES.items():
-        if not only or n in only:
+        if n in only:
             write(f'body_s{n}', body(ev), note)
     write('last', body(None), 'last k-tile of an output tile')
