@@ -314,6 +314,19 @@ int mg_vae_upconv_fold_weights_f32(const float* w, int Cout, int Cin, float* wp,
 int mg_vae_upconv_phases_f32(const float* x, int T, int H, int W, int Cin, const float* wp, const float* bias, int Cout,
                              float* out, int mode, void* stream);
 
+/* Column-window forms (ABI 9) — one rank's W band of a decode split along W over several GPUs (no reference counterpart: the
+ * reference decodes on rank 0 alone, wan/text2video.py:260-261; SURVEY.md 8(e) names the spatial split with one halo pixel per
+ * convolution as the natural sharding).  x and cache are the band WITH the neighbours' halo columns: [.][H][W][Cin] where W counts
+ * the halos; the launch computes the output columns [col0, col0 + cols) only and writes them compactly — out / residual
+ * [T][H][cols][Cout] (phases: out [T][2H][2 cols][Cout]); the zero padding of the reference begins outside [0, W) of x, i.e. at
+ * the true image border of an edge rank.  Every output voxel is the same dot product in the same order as in the full launch: the
+ * bands of P ranks, side by side, are bit-identical to mg_vae_conv_f32 / mg_vae_upconv_phases_f32 on the whole image. */
+int mg_vae_conv_cols_f32(const float* x, const float* cache, int tc, int T, int H, int W, int Cin,
+                         const float* w, const float* bias, int Cout, int kt, int kh, int kw,
+                         const float* residual, float* out, int col0, int cols, int mode, void* stream);
+int mg_vae_upconv_phases_cols_f32(const float* x, int T, int H, int W, int Cin, const float* wp, const float* bias, int Cout,
+                                  float* out, int col0, int cols, int mode, void* stream);
+
 /* `mode` of mg_vae_conv_f32 / mg_vae_upconv_phases_f32 — the arithmetic of THAT call (ABI 7: an argument, not a
  * process-global switch; anything else returns MG_ERR_ARG):
  *   MG_VAE_EXACT  = v_mfma_f32_32x32x2_f32, bitwise an fmaf chain — the reference's fp32 arithmetic (vae.py:623,658);
@@ -342,6 +355,12 @@ int mg_vae_rmsnorm_silu_f32(const float* x, const float* gamma, float* out, int6
 int64_t mg_vae_attn_workspace_floats(int64_t L, int C);
 int mg_vae_attn_f32(const float* qkv, float* out, int frames, int64_t L, int C, float* workspace,
                     void* stream);
+/* The same attention for Lq <= Lk query rows of a frame against all Lk keys / values held elsewhere (ABI 9; the W-band decode: q =
+ * the band's own pixels, k / v = the two halves of the all-gathered k|v tensor): q [frames][Lq][..] row stride ldq, k / v
+ * [frames][Lk][..] row stride ldkv, out [frames][Lq][C]; workspace mg_vae_attn_workspace_floats(Lk, C).  A row's bits do not
+ * depend on which other rows are computed with it. */
+int mg_vae_attn_rows_f32(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, float* out, int frames,
+                         int64_t Lq, int64_t Lk, int C, float* workspace, void* stream);
 
 /* z[C][T][H][W] (NCTHW, reference layout) -> channels-last with the latent un-normalisation
  * z/scale1[c] + scale0[c] of vae.py:546-551; and the inverse layout change with clamp(-1,1) for

@@ -42,6 +42,10 @@ struct ConvArgs {
     const float* residual; float* out; int64_t ldo; int Ho, Wo; int64_t M; float out_scale;
     int phases = 0; int64_t w_phase_stride = 0;      // phases: blockIdx.z = 2 py + px is one of the four 2x2 phase convolutions (below)
     int ksplit = 0; int64_t part_stride = 0;         // ksplit > 1 (1x1x1 GEMMs only): blockIdx.z = K slice, raw partial sums go to out + z * part_stride
+    int xw0 = 0;                                     // column window (mg_vae_conv_cols_f32 / mg_vae_upconv_phases_cols_f32: a rank's W band of a decode split over GPUs):
+                                                     // the conv grid is Ho x Wo with Wo <= W columns, its column c reads input column xw0 + c (+ tap offset); the zero
+                                                     // padding begins outside [0, W) of the INPUT, whose columns left and right of the window are the neighbours' halos;
+                                                     // out / residual are compact ([.][Ho][Wo], phases: [.][2 H][2 Wo]).  Not with up2.
 };
 
 // Output epilogue shared by both conv kernels: lane (l31, g) owns voxel row m and, per cout block nb and quad rq, the four
@@ -179,10 +183,10 @@ __global__ __launch_bounds__(CV_THREADS) void vae_conv_kernel(const ConvArgs a) 
         const int valid = vt_[i] >= 0;                               // rows past M: every tap reads the zero page (never stored)
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            const int ti = vt_[i] + d - (a.kt - 1), yy = vy_[i] + d + oy, xx = vx_[i] + d + ox;
+            const int ti = vt_[i] + d - (a.kt - 1), yy = vy_[i] + d + oy, xx = vx_[i] + a.xw0 + d + ox;
             mk |= (unsigned)(valid & (d < a.kt) & ((ti >= 0) | (has_cache & (a.tc + ti >= 0)))) << d;
             mk |= (unsigned)(valid & (d < a.kh) & (yy >= 0) & (yy < a.Ho)) << (3 + d);
-            mk |= (unsigned)(valid & (d < a.kw) & (xx >= 0) & (xx < a.Wo)) << (6 + d);
+            mk |= (unsigned)(valid & (d < a.kw) & (xx >= 0) & (xx < a.W)) << (6 + d);      // (this mask serves the paths without up2: input width = W)
         }
         vmask[i] = mk;
         fbc[i] = a.x;
@@ -195,7 +199,7 @@ __global__ __launch_bounds__(CV_THREADS) void vae_conv_kernel(const ConvArgs a) 
                 for (int i = 0; i < NR; ++i) {
                     const int ti = vt_[i] + ld_dt - (a.kt - 1);
                     const int tt = max(ti >= 0 ? ti : a.tc + ti, 0);
-                    const int vox = (tt * a.H + vy_[i]) * a.W + vx_[i];       // only dereferenced when the row's bits are set
+                    const int vox = (tt * a.H + vy_[i]) * a.W + vx_[i] + a.xw0;       // only dereferenced when the row's bits are set
                     fbc[i] = (ti >= 0 ? a.x : base_neg) + (int64_t)max(vox, 0) * a.ldx;
                 }
             }
@@ -368,11 +372,11 @@ __global__ __launch_bounds__(CV_THREADS) void vae_conv_kernel(const ConvArgs a) 
 
     auto out_row = [&](int64_t m_in) __attribute__((always_inline)) {       // row of out / residual of conv-grid voxel m_in
         if (!a.phases || m_in >= a.M) return m_in;
-        const int64_t hw = (int64_t)a.H * a.W;
+        const int64_t hw = (int64_t)a.H * a.Wo;                                   // the conv grid: H x Wo (Wo = W unless a column window)
         const int t = (int)(m_in / hw);
         const int rem = (int)(m_in - (int64_t)t * hw);
-        const int y = rem / a.W, x = rem - y * a.W;
-        return ((int64_t)t * 2 * a.H + 2 * y + (ph >> 1)) * (2 * a.W) + 2 * x + (ph & 1);
+        const int y = rem / a.Wo, x = rem - y * a.Wo;
+        return ((int64_t)t * 2 * a.H + 2 * y + (ph >> 1)) * (2 * a.Wo) + 2 * x + (ph & 1);
     };
     if (NB == 0) {
         // the two lane halves hold the even / odd float4 of every 8 channels of the same voxel: add them, then lanes 0-31
@@ -463,10 +467,11 @@ static int launch_conv(const ConvArgs& a, hipStream_t st, int mode) {
     return mg_check_launch();
 }
 
-extern "C" int mg_vae_conv_f32(const float* x, const float* cache, int tc, int T, int H, int W, int Cin,
-                               const float* w, const float* bias, int Cout, int kt, int kh, int kw, int up2,
-                               const float* residual, float* out, int mode, void* stream) {
+static int vae_conv_impl(const float* x, const float* cache, int tc, int T, int H, int W, int Cin,
+                         const float* w, const float* bias, int Cout, int kt, int kh, int kw, int up2,
+                         const float* residual, float* out, int col0, int cols, int mode, void* stream) {
     if (!x || !w || !out) return MG_ERR_ARG;
+    if (col0 < 0 || cols <= 0 || col0 + cols > W || (up2 && (col0 || cols != W))) return MG_ERR_SHAPE;
     if (T <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 3) || Cout <= 0 || kt < 1 || kh < 1 || kw < 1 ||
         !(kh & 1) || !(kw & 1) || tc < 0 || tc > kt - 1 || (tc > 0 && !cache))
         return MG_ERR_SHAPE;
@@ -480,9 +485,23 @@ extern "C" int mg_vae_conv_f32(const float* x, const float* cache, int tc, int T
     a.x = x; a.cache = cache; a.tc = tc; a.T = T; a.H = H; a.W = W; a.Cin = Cin; a.ldx = Cin;
     a.w = w; a.ldw = (int64_t)kt * kh * kw * Cin; a.bias = bias; a.Cout = Cout; a.kt = kt; a.kh = kh; a.kw = kw;
     a.up2 = up2 ? 1 : 0; a.residual = residual; a.out = out; a.ldo = Cout;
-    a.Ho = up2 ? 2 * H : H; a.Wo = up2 ? 2 * W : W; a.M = (int64_t)T * a.Ho * a.Wo; a.out_scale = 1.f;
-    a.phases = 0; a.w_phase_stride = 0;
+    a.Ho = up2 ? 2 * H : H; a.Wo = up2 ? 2 * W : cols; a.M = (int64_t)T * a.Ho * a.Wo; a.out_scale = 1.f;
+    a.phases = 0; a.w_phase_stride = 0; a.xw0 = col0;
     return launch_conv(a, (hipStream_t)stream, mode);
+}
+
+extern "C" int mg_vae_conv_f32(const float* x, const float* cache, int tc, int T, int H, int W, int Cin,
+                               const float* w, const float* bias, int Cout, int kt, int kh, int kw, int up2,
+                               const float* residual, float* out, int mode, void* stream) {
+    return vae_conv_impl(x, cache, tc, T, H, W, Cin, w, bias, Cout, kt, kh, kw, up2, residual, out, 0, W, mode, stream);
+}
+
+// the same convolution for the output columns [col0, col0 + cols) only, written compactly (out / residual [T][H][cols][Cout]): one rank's band of a
+// decode split along W over several GPUs — x and cache are the band WITH its halo columns, the zero padding starts outside [0, W) of them
+extern "C" int mg_vae_conv_cols_f32(const float* x, const float* cache, int tc, int T, int H, int W, int Cin,
+                                    const float* w, const float* bias, int Cout, int kt, int kh, int kw,
+                                    const float* residual, float* out, int col0, int cols, int mode, void* stream) {
+    return vae_conv_impl(x, cache, tc, T, H, W, Cin, w, bias, Cout, kt, kh, kw, 0, residual, out, col0, cols, mode, stream);
 }
 
 // w [Cout][1][3][3][Cin] -> wp [4 phases = 2 py + px][Cout][2][2][Cin]: the taps of a 3x3 kernel that fall on the same image
@@ -512,18 +531,29 @@ extern "C" int mg_vae_upconv_fold_weights_f32(const float* w, int Cout, int Cin,
     return mg_check_launch();
 }
 
-extern "C" int mg_vae_upconv_phases_f32(const float* x, int T, int H, int W, int Cin, const float* wp, const float* bias,
-                                        int Cout, float* out, int mode, void* stream) {
+static int vae_upconv_phases_impl(const float* x, int T, int H, int W, int Cin, const float* wp, const float* bias,
+                                  int Cout, float* out, int col0, int cols, int mode, void* stream) {
     if (!x || !wp || !out) return MG_ERR_ARG;
-    if (T <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 3) || Cout <= 0) return MG_ERR_SHAPE;
+    if (T <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 3) || Cout <= 0 || col0 < 0 || cols <= 0 || col0 + cols > W) return MG_ERR_SHAPE;
     if (((uintptr_t)x & 15) || ((uintptr_t)wp & 15) || ((uintptr_t)out & 15) || (bias && ((uintptr_t)bias & 15))) return MG_ERR_SHAPE;
     if ((int64_t)T * 4 * H * W > 0x7fffffffLL) return MG_ERR_SHAPE;      // output voxels stay 32-bit like every other conv's
     ConvArgs a;
     a.x = x; a.cache = nullptr; a.tc = 0; a.T = T; a.H = H; a.W = W; a.Cin = Cin; a.ldx = Cin;
     a.w = wp; a.ldw = (int64_t)4 * Cin; a.bias = bias; a.Cout = Cout; a.kt = 1; a.kh = 2; a.kw = 2; a.up2 = 0;
-    a.residual = nullptr; a.out = out; a.ldo = Cout; a.Ho = H; a.Wo = W; a.M = (int64_t)T * H * W; a.out_scale = 1.f;
-    a.phases = 1; a.w_phase_stride = (int64_t)Cout * 4 * Cin;
+    a.residual = nullptr; a.out = out; a.ldo = Cout; a.Ho = H; a.Wo = cols; a.M = (int64_t)T * H * cols; a.out_scale = 1.f;
+    a.phases = 1; a.w_phase_stride = (int64_t)Cout * 4 * Cin; a.xw0 = col0;
     return launch_conv(a, (hipStream_t)stream, mode);
+}
+
+extern "C" int mg_vae_upconv_phases_f32(const float* x, int T, int H, int W, int Cin, const float* wp, const float* bias,
+                                        int Cout, float* out, int mode, void* stream) {
+    return vae_upconv_phases_impl(x, T, H, W, Cin, wp, bias, Cout, out, 0, W, mode, stream);
+}
+
+// the same for the image columns [col0, col0 + cols) only: out [T][2 H][2 cols][Cout] (a rank's band; x carries the halo columns)
+extern "C" int mg_vae_upconv_phases_cols_f32(const float* x, int T, int H, int W, int Cin, const float* wp, const float* bias,
+                                             int Cout, float* out, int col0, int cols, int mode, void* stream) {
+    return vae_upconv_phases_impl(x, T, H, W, Cin, wp, bias, Cout, out, col0, cols, mode, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -641,11 +671,15 @@ extern "C" int64_t mg_vae_attn_workspace_floats(int64_t L, int C) {
     return (qb + C) * Lp + VAE_ATTN_KSPLIT * qb * C;
 }
 
-extern "C" int mg_vae_attn_f32(const float* qkv, float* out, int frames, int64_t L, int C, float* workspace,
-                               void* stream) {
-    if (!qkv || !out || !workspace) return MG_ERR_ARG;
-    if (frames <= 0 || L <= 0 || C <= 0 || (C & 3) || L > 0x7ffffff0LL) return MG_ERR_SHAPE;
-    if ((uintptr_t)workspace & 15) return MG_ERR_SHAPE;
+// General form: Lq query rows (row stride ldq, frame stride q_fs) against Lk keys / values (row stride ldkv, frame stride kv_fs), out [frames][Lq][C].
+// A row's result does not depend on which other rows are computed with it (one dot product per score in a fixed order, a row-local softmax, P.V in
+// VAE_ATTN_KSPLIT K slices of the same Lk added in a fixed order): a rank of a decode split along W computes the rows of its own pixels against the
+// gathered keys / values and gets the bits of the one-GPU launch.
+static int vae_attn_impl(const float* q, int64_t ldq, int64_t q_fs, const float* k, const float* v, int64_t ldkv, int64_t kv_fs, float* out,
+                         int frames, int64_t Lq, int64_t L, int C, float* workspace, void* stream) {
+    if (!q || !k || !v || !out || !workspace) return MG_ERR_ARG;
+    if (frames <= 0 || L <= 0 || Lq <= 0 || Lq > L || C <= 0 || (C & 3) || L > 0x7ffffff0LL || (ldq & 3) || (ldkv & 3)) return MG_ERR_SHAPE;
+    if (((uintptr_t)workspace & 15) || ((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15)) return MG_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     const int64_t Lp = (L + 3) & ~(int64_t)3;  // row stride of S / V^T, 16-byte aligned rows
     const int64_t QB = L < VAE_ATTN_QB ? L : VAE_ATTN_QB;
@@ -653,22 +687,23 @@ extern "C" int mg_vae_attn_f32(const float* qkv, float* out, int frames, int64_t
     float* vT = workspace + QB * Lp;      // [C][Lp]
     float* part = vT + (int64_t)C * Lp;   // [KSPLIT][QB][C] partial sums of P.V
     for (int f = 0; f < frames; ++f) {
-        const float* base = qkv + (int64_t)f * L * 3 * C;
+        const float* qf = q + (int64_t)f * q_fs;
+        const float* kf = k + (int64_t)f * kv_fs;
         hipLaunchKernelGGL(transpose_f32_kernel, dim3((unsigned)((Lp + 31) / 32), (unsigned)((C + 31) / 32)),
-                           dim3(32, 8), 0, st, base + 2 * C, (int64_t)3 * C, vT, L, C, Lp);
-        for (int64_t q0 = 0; q0 < L; q0 += QB) {
-            const int64_t nq = L - q0 < QB ? L - q0 : QB;
+                           dim3(32, 8), 0, st, v + (int64_t)f * kv_fs, ldkv, vT, L, C, Lp);
+        for (int64_t q0 = 0; q0 < Lq; q0 += QB) {
+            const int64_t nq = Lq - q0 < QB ? Lq - q0 : QB;
             ConvArgs a;
             // S[nq][L] = q[q0.. ][C] . k[L][C]^T * C^-1/2
-            a.x = base + q0 * 3 * C; a.cache = nullptr; a.tc = 0; a.T = 1; a.H = 1; a.W = (int)nq; a.Cin = C; a.ldx = 3 * C;
-            a.w = base + C; a.ldw = 3 * C; a.bias = nullptr; a.Cout = (int)L; a.kt = a.kh = a.kw = 1; a.up2 = 0;
+            a.x = qf + q0 * ldq; a.cache = nullptr; a.tc = 0; a.T = 1; a.H = 1; a.W = (int)nq; a.Cin = C; a.ldx = ldq;
+            a.w = kf; a.ldw = ldkv; a.bias = nullptr; a.Cout = (int)L; a.kt = a.kh = a.kw = 1; a.up2 = 0;
             a.residual = nullptr; a.out = S; a.ldo = Lp; a.Ho = 1; a.Wo = (int)nq; a.M = nq;
             a.out_scale = 1.f / sqrtf((float)C);
             int rc = launch_conv(a, st, MG_VAE_EXACT);     // the attention block's two GEMMs are exact in either mode
             if (rc) return rc;
             hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)nq), dim3(256), 0, st, S, L, Lp);
             // out[nq][C] = P[nq][Lp] . vT[C][Lp]^T   (padding columns are zero on both sides)
-            float* dst = out + ((int64_t)f * L + q0) * C;
+            float* dst = out + ((int64_t)f * Lq + q0) * C;
             a.x = S; a.ldx = Lp; a.Cin = (int)Lp; a.w = vT; a.ldw = Lp; a.Cout = C; a.out = dst;
             a.ldo = C; a.out_scale = 1.f;
             const int Z = (int)vae_attn_ksplit(nq, C);
@@ -686,6 +721,19 @@ extern "C" int mg_vae_attn_f32(const float* qkv, float* out, int frames, int64_t
         }
     }
     return mg_check_launch();
+}
+
+extern "C" int mg_vae_attn_f32(const float* qkv, float* out, int frames, int64_t L, int C, float* workspace,
+                               void* stream) {
+    if (!qkv) return MG_ERR_ARG;
+    return vae_attn_impl(qkv, 3 * (int64_t)C, L * 3 * C, qkv + C, qkv + 2 * C, 3 * (int64_t)C, L * 3 * C, out, frames, L, L, C, workspace, stream);
+}
+
+// rows of ONE band: q [frames][Lq][>= C] (row stride ldq), k / v [frames][Lk][..] (row stride ldkv, e.g. the two halves of a gathered k|v tensor),
+// out [frames][Lq][C]; workspace: mg_vae_attn_workspace_floats(Lk, C) floats
+extern "C" int mg_vae_attn_rows_f32(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, float* out, int frames,
+                                    int64_t Lq, int64_t Lk, int C, float* workspace, void* stream) {
+    return vae_attn_impl(q, ldq, Lq * ldq, k, v, ldkv, Lk * ldkv, out, frames, Lq, Lk, C, workspace, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

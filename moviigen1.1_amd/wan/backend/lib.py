@@ -48,9 +48,13 @@ SIGNATURES = {
                         c_int, c_vp, c_vp, c_int, c_vp],
     'mg_vae_upconv_fold_weights_f32': [c_vp, c_int, c_int, c_vp, c_vp],
     'mg_vae_upconv_phases_f32': [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_int, c_vp],
+    'mg_vae_conv_cols_f32': [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int,
+                             c_vp, c_vp, c_int, c_int, c_int, c_vp],
+    'mg_vae_upconv_phases_cols_f32': [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp],
     'mg_vae_rmsnorm_silu_f32': [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp],
     'mg_vae_attn_workspace_floats': [c_i64, c_int],
     'mg_vae_attn_f32': [c_vp, c_vp, c_int, c_i64, c_int, c_vp, c_vp],
+    'mg_vae_attn_rows_f32': [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_int, c_i64, c_i64, c_int, c_vp, c_vp],
     'mg_vae_latent_in_f32': [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp],
     'mg_vae_video_out_f32': [c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_int, c_vp],
     'mg_vae_time_interleave_f32': [c_vp, c_int, c_i64, c_int, c_vp, c_vp],

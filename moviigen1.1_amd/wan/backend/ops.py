@@ -231,6 +231,23 @@ def vae_conv(x, w, bias, out, kt, kh, kw, cache=None, up2=False, residual=None, 
     return out
 
 
+def vae_conv_cols(x, w, bias, out, kt, kh, kw, col0, cache=None, residual=None, mode=VAE_EXACT):
+    """the W-band form: x [T,H,W,Cin] and cache carry the neighbours' halo columns; out (and residual) [T,H,cols,Cout] compact =
+    the output columns [col0, col0 + cols) of vae_conv on the whole image."""
+    for n, t in (('x', x), ('w', w), ('bias', bias), ('out', out), ('cache', cache), ('residual', residual)):
+        _chk(t, torch.float32, n)
+    T, H, W, Cin = x.shape
+    cols = out.shape[2]
+    if out.shape[0] != T or out.shape[1] != H or not out.is_contiguous() or not x.is_contiguous():
+        raise lib.MoviigenHipError(f'vae_conv_cols: out {tuple(out.shape)} does not match x {tuple(x.shape)}')
+    if cache is not None and (tuple(cache.shape[1:]) != tuple(x.shape[1:]) or not cache.is_contiguous()):
+        raise lib.MoviigenHipError('vae_conv_cols: the cache must have the haloed geometry of x')
+    tc = 0 if cache is None else cache.shape[0]
+    lib.call('mg_vae_conv_cols_f32', _p(x), _p(cache), tc, T, H, W, Cin, _p(w), _p(bias), w.shape[0], kt, kh, kw,
+             _p(residual), _p(out), int(col0), int(cols), int(mode), _st())
+    return out
+
+
 def vae_upconv_fold_weights(w):
     """w [Cout,1,3,3,Cin] (the conv behind a nearest-2x upsample) -> [4,Cout,2,2,Cin]: one 2x2 kernel per output parity."""
     _chk(w, torch.float32, 'w')
@@ -251,6 +268,18 @@ def vae_upconv_phases(x, wp, bias, out, mode=VAE_EXACT):
     return out
 
 
+def vae_upconv_phases_cols(x, wp, bias, out, col0, mode=VAE_EXACT):
+    """the W-band form of vae_upconv_phases: x [T,H,W,Cin] with halo columns, out [T,2H,2 cols,Cout] compact."""
+    for n, t in (('x', x), ('wp', wp), ('bias', bias), ('out', out)):
+        _chk(t, torch.float32, n)
+    T, H, W, Cin = x.shape
+    if out.shape[0] != T or out.shape[1] != 2 * H or out.shape[2] % 2 or not out.is_contiguous() or not x.is_contiguous():
+        raise lib.MoviigenHipError(f'vae_upconv_phases_cols: out {tuple(out.shape)} does not match x {tuple(x.shape)}')
+    lib.call('mg_vae_upconv_phases_cols_f32', _p(x), T, H, W, Cin, _p(wp), _p(bias), wp.shape[1], _p(out), int(col0), out.shape[2] // 2,
+             int(mode), _st())
+    return out
+
+
 def vae_rmsnorm_silu(x, gamma, out, do_silu=True):
     C = x.shape[-1]
     lib.call('mg_vae_rmsnorm_silu_f32', _p(x), _p(gamma), _p(out), x.numel() // C, C, int(do_silu), _st())
@@ -266,6 +295,22 @@ def vae_attn(qkv, out, workspace):
     if workspace.numel() < vae_attn_workspace_floats(L, C3 // 3):
         raise lib.MoviigenHipError('vae_attn workspace too small')
     lib.call('mg_vae_attn_f32', _p(qkv), _p(out), frames, L, C3 // 3, _p(workspace), _st())
+    return out
+
+
+def vae_attn_rows(q, kv, out, workspace):
+    """q [frames, Lq, >= C] (a column slice of the band's q|k|v is fine), kv [frames, Lk, 2C] = k | v of ALL pixels of the frame in image
+    order, out [frames, Lq, C]: the band's rows of vae_attn, same bits."""
+    for n, t in (('q', q), ('kv', kv), ('out', out), ('workspace', workspace)):
+        _chk(t, torch.float32, n)
+    frames, Lq = q.shape[:2]
+    Lk, C = kv.shape[1], kv.shape[2] // 2
+    if kv.shape[0] != frames or not kv.is_contiguous() or not out.is_contiguous() or q.stride(0) != Lq * q.stride(1) or out.shape != (frames, Lq, C):
+        raise lib.MoviigenHipError('vae_attn_rows: shapes')
+    if workspace.numel() < vae_attn_workspace_floats(Lk, C):
+        raise lib.MoviigenHipError('vae_attn workspace too small')
+    lib.call('mg_vae_attn_rows_f32', _p(q), q.stride(1), _p(kv), ctypes.c_void_p(kv.data_ptr() + 4 * C), 2 * C, _p(out), frames, Lq, Lk, C,
+             _p(workspace), _st())
     return out
 
 

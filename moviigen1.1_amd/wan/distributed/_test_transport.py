@@ -84,6 +84,16 @@ class RingHop:
             d.copy_(h)
 
 
+def neighbor_exchange(sends, recvs, group):
+    host_r = [torch.empty(t.shape, dtype=t.dtype) for t, _ in recvs]
+    ops = [dist.P2POp(dist.isend, t.detach().cpu().contiguous(), r, group) for t, r in sends] + \
+          [dist.P2POp(dist.irecv, h, r, group) for h, (_, r) in zip(host_r, recvs)]
+    for w in dist.batch_isend_irecv(ops):
+        w.wait()
+    for h, (t, _) in zip(host_r, recvs):
+        t.copy_(h)
+
+
 def rendezvous(group):
     if isinstance(group, EmulatedGroup):
         return

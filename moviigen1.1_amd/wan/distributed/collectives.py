@@ -74,6 +74,22 @@ def recv(shape, src, device, group=None):
     return x
 
 
+def neighbor_exchange(sends, recvs, group=None):
+    """one batched point-to-point exchange: sends = [(contiguous tensor, group rank)], recvs = [(tensor to fill, group rank)] — the halo columns
+    of the W-band VAE decode go to / come from the left and right neighbour in ONE group of isend / irecv (no ordering between the two directions:
+    a chain of blocking pairs would unroll rank by rank).  Stream-ordered on return."""
+    if not sends and not recvs:
+        return
+    probe = (sends or recvs)[0][0]
+    world = group is None or group is dist.group.WORLD
+    gr = (lambda r: r) if world else (lambda r: dist.get_global_rank(group, r))
+    if _test_transport.staged(probe, group):
+        return _test_transport.neighbor_exchange([(t, gr(r)) for t, r in sends], [(t, gr(r)) for t, r in recvs], group)
+    ops = [dist.P2POp(dist.isend, t, gr(r), group) for t, r in sends] + [dist.P2POp(dist.irecv, t, gr(r), group) for t, r in recvs]
+    for w in dist.batch_isend_irecv(ops):
+        w.wait()
+
+
 class _Works:
     def __init__(self, works):
         self.works = works

@@ -30,6 +30,67 @@ _STD = [2.8184, 1.4541, 2.3275, 2.6558, 1.2196, 1.7708, 2.6052, 2.0743,
         3.2687, 2.1526, 2.8652, 1.5579, 1.6382, 1.1253, 2.8251, 1.9160]
 
 
+class _Band:
+    """One rank's band of image columns in the W-split multi-GPU decode (`WanVAE_.decode_spatial`): rank r of P owns the latent columns
+    [starts[r], starts[r] + widths[r]) — widths differ by at most one — and the same band, scaled, of every later activation."""
+
+    def __init__(self, group, P, rank, W):
+        base, extra = divmod(W, P)
+        if base < 1:
+            raise ValueError(f'decode_spatial: {P} ranks need at least {P} latent columns, the latent has {W}')
+        self.widths = [base + (1 if r < extra else 0) for r in range(P)]
+        self.starts = [sum(self.widths[:r]) for r in range(P)]
+        self.group, self.P, self.rank = group, P, rank
+        self.left = rank - 1 if rank > 0 else None
+        self.right = rank + 1 if rank < P - 1 else None
+        self.scale = 1                     # 2x per spatial up-sampler passed
+        self.halo_bytes = 0                # what this rank sent as halos (reported by tools/bench_vae.py)
+
+    def halo(self, x):
+        """x [T,H,Wl,C] -> (x with the neighbours' border columns attached: [T,H,nl+Wl+nr,C], nl).  One halo column per side is what a
+        3x3 convolution reads across the cut; an edge rank has no neighbour on that side — there the convolution's own
+        zero padding is the reference's."""
+        from ..distributed import collectives
+        T, H, Wl, C = x.shape
+        nl, nr = int(self.left is not None), int(self.right is not None)
+        xh = x.new_empty(T, H, nl + Wl + nr, C)
+        xh[:, :, nl:nl + Wl].copy_(x)
+        sends, recvs = [], []
+        lbuf = rbuf = None
+        if nl:
+            sends.append((x[:, :, :1].contiguous(), self.left))
+            lbuf = x.new_empty(T, H, 1, C)
+            recvs.append((lbuf, self.left))
+        if nr:
+            sends.append((x[:, :, -1:].contiguous(), self.right))
+            rbuf = x.new_empty(T, H, 1, C)
+            recvs.append((rbuf, self.right))
+        collectives.neighbor_exchange(sends, recvs, self.group)
+        self.halo_bytes += sum(t.numel() * 4 for t, _ in sends)
+        if nl:
+            xh[:, :, :1].copy_(lbuf)
+        if nr:
+            xh[:, :, -1:].copy_(rbuf)
+        return xh, nl
+
+    def gather_cols(self, t):
+        """t [T,H,Wl,K] (this band) -> [T,H,W,K] of all bands in image order, on every rank (the attention block's keys / values)."""
+        from ..distributed import collectives
+        T, H, Wl, K = t.shape
+        ws = [w * self.scale for w in self.widths]
+        wmax = max(ws)
+        mine = t.new_zeros(T, H, wmax, K)
+        mine[:, :, :Wl].copy_(t)
+        parts = t.new_empty(self.P, T, H, wmax, K)
+        collectives.all_gather(parts, mine, self.group)
+        full = t.new_empty(T, H, sum(ws), K)
+        c = 0
+        for r in range(self.P):
+            full[:, :, c:c + ws[r]].copy_(parts[r][:, :, :ws[r]])
+            c += ws[r]
+        return full
+
+
 class WanVAE_:
     """decoder-side container: parameters keyed by the reference state_dict names, repacked for
     the channels-last kernels ([Cout,Cin,kt,kh,kw] -> [Cout,kt,kh,kw,Cin])."""
@@ -73,6 +134,7 @@ class WanVAE_:
                            'resample' not in k and 'to_qkv' not in k and 'proj' not in k)
         self.mean = torch.tensor(_MEAN[:z_dim], dtype=torch.float32, device=self.device)
         self.inv_std = (1.0 / torch.tensor(_STD[:z_dim], dtype=torch.float32)).to(self.device)
+        self._band = None                  # set for the duration of a decode_spatial call: this rank's column band
 
     # ---- building blocks -----------------------------------------------------------------------
     def _new(self, *shape):
@@ -90,13 +152,25 @@ class WanVAE_:
         """the feat_cache protocol of every 3x3x3 conv (reference vae.py:205-217)."""
         i = idx[0]
         prev = cache[i]
+        col0 = None
+        if self._band is not None:
+            # W-band decode: the convolution reads one column across each cut — fetch the neighbours' border columns first; the causal cache
+            # keeps the frames WITH their halos (so nothing is exchanged twice)
+            cols = x.shape[2]
+            x, col0 = self._band.halo(x)
         if x.shape[0] >= CACHE_T:
             cx = x[-CACHE_T:].clone()
         elif prev is not None:
             cx = torch.cat([prev[-1:], x[-1:]], dim=0)
         else:
             cx = x[-1:].clone()
-        out = self._conv(name, x, cache=prev, residual=residual)
+        if col0 is None:
+            out = self._conv(name, x, cache=prev, residual=residual)
+        else:
+            w = self.P[name + '.weight']
+            kt, kh, kw = w.shape[1:4]
+            out = ops.vae_conv_cols(x, w, self.P[name + '.bias'], self._new(x.shape[0], x.shape[1], cols, w.shape[0]), kt, kh, kw, col0,
+                                    cache=prev, residual=residual, mode=self._conv_mode)
         cache[i] = cx
         idx[0] += 1
         return out
@@ -119,6 +193,14 @@ class WanVAE_:
         y = self._norm_silu(x, pre + 'norm.gamma', silu=False)
         qkv = self._conv(pre + 'to_qkv', y)
         a = self._new(T, H, W, C)
+        if self._band is not None:
+            # W-band decode: queries = this band's pixels, keys / values = every band's (one all-gather of k|v per chunk); a row's result does
+            # not depend on which rows are computed with it (mg_vae_attn_rows_f32)
+            kv = self._band.gather_cols(qkv[..., C:])
+            Lk = kv.shape[1] * kv.shape[2]
+            ws = self._new(ops.vae_attn_workspace_floats(Lk, C))
+            ops.vae_attn_rows(qkv.view(T, L, 3 * C)[..., :C], kv.view(T, Lk, 2 * C), a.view(T, L, C), ws)
+            return self._conv(pre + 'proj', a, residual=x)
         ws = self._new(ops.vae_attn_workspace_floats(L, C))
         ops.vae_attn(qkv.view(T, L, 3 * C), a.view(T, L, C), ws)
         return self._conv(pre + 'proj', a, residual=x)
@@ -143,12 +225,18 @@ class WanVAE_:
                 T, H, W, C2 = y.shape
                 x = ops.vae_time_interleave(y, self._new(2 * T, H, W, C2 // 2))
         if self.upconv == 'gather':
+            if self._band is not None:
+                raise NotImplementedError("decode_spatial runs the up-sampling convolutions as phase convolutions (upconv='phases')")
             return self._conv(pre + 'resample.1', x, up2=True)
         name = pre + 'resample.1'
         wp = self.P.get(name + '.phases')
         if wp is None:                                   # folded once per checkpoint
             wp = self.P[name + '.phases'] = ops.vae_upconv_fold_weights(self.P[name + '.weight'])
         T, H, W, _ = x.shape
+        if self._band is not None:
+            xh, col0 = self._band.halo(x)
+            self._band.scale *= 2
+            return ops.vae_upconv_phases_cols(xh, wp, self.P[name + '.bias'], self._new(T, 2 * H, 2 * W, wp.shape[1]), col0, mode=self._conv_mode)
         return ops.vae_upconv_phases(x, wp, self.P[name + '.bias'], self._new(T, 2 * H, 2 * W, wp.shape[1]), mode=self._conv_mode)
 
     # ---- the decoder as a list of stages (each owns a contiguous range of feat_cache slots) ---------
@@ -274,6 +362,55 @@ class WanVAE_:
                 k = 'narrow' if cout == base else 'wide'
             out.append(c * REL_MS_PER_MAC[k])
         return out
+
+    @torch.no_grad()
+    def decode_spatial(self, z, group=None, chunks=None):
+        """Multi-GPU decode split along W (the reference decodes on rank 0 alone, wan/text2video.py:260-261 ->
+        vae.py:544-568): rank r owns a band of image columns of EVERY activation and runs the whole decoder on it, chunk by chunk with the
+        single-GPU chunk list and its own causal caches.  What crosses ranks: one halo column per side in front of every 3x3 convolution
+        (T x H x C floats per side, `_Band.halo`), the attention block's keys / values (one all-gather per chunk at latent resolution), and at
+        the end each band of the video to rank 0.  All P ranks compute all the time — unlike the layer pipeline (`decode_pipelined`), whose
+        six chunks through eight segments are mostly fill and drain.  Every output voxel is the same dot product in the same order as in the
+        one-GPU launch: the video on rank 0 is bit-identical to `decode` (tests/dist_vae_worker.py, 2 / 4 / 8 ranks, uneven bands).
+        Every rank passes the same latent; returns the video on rank 0, None elsewhere."""
+        import torch.distributed as dist
+        from ..distributed import collectives
+        P, rank = dist.get_world_size(group), dist.get_rank(group)
+        if P == 1:
+            return self.decode(z, chunks)
+        z = z.to(self.device, torch.float32)
+        C, T, H, W = z.shape
+        band = _Band(group, P, rank, W)
+        c0, wl = band.starts[rank], band.widths[rank]
+        chunks = self._chunks(T, chunks)
+        self._band = band
+        try:
+            zb = z[:, :, :, c0:c0 + wl].contiguous()
+            x = ops.vae_latent_in(zb, self.mean, self.inv_std, self._new(T, H, wl, C))
+            x = self._conv('conv2', x)                                  # 1x1x1: no halo
+            cache = [None] * (self.n_slots + 8)
+            mine = self._new(3, 1 + 4 * (T - 1), 8 * H, 8 * wl)         # this band of the video
+            t0, f0 = 0, 0
+            for n in chunks:
+                band.scale = 1
+                y = self._decoder_chunk(x[t0:t0 + n], cache)
+                ops.vae_video_out(y, mine, f0)
+                t0 += n
+                f0 += y.shape[0]
+            assert f0 == mine.shape[1] and band.scale == 8
+        finally:
+            self._band = None
+        self.last_halo_bytes = band.halo_bytes
+        if rank != 0:
+            collectives.send(mine, 0 if group is None else dist.get_global_rank(group, 0), group)
+            return None
+        video = self._new(3, mine.shape[1], 8 * H, 8 * W)
+        video[:, :, :, :8 * wl].copy_(mine)
+        for r in range(1, P):
+            part = collectives.recv((3, mine.shape[1], 8 * H, 8 * band.widths[r]), r if group is None else dist.get_global_rank(group, r),
+                                    self.device, group)
+            video[:, :, :, 8 * band.starts[r]:8 * (band.starts[r] + band.widths[r])].copy_(part)
+        return video
 
     @torch.no_grad()
     def decode_pipelined(self, z, group=None, chunks=None, stage_ms=None):
@@ -441,5 +578,9 @@ class WanVAE:
         return video + 8 * act
 
     def decode_pipelined(self, zs, group=None):
-        """multi-GPU decode: every rank calls it with the same latents; videos on rank 0, None elsewhere."""
+        """multi-GPU decode, layer pipeline: every rank calls it with the same latents; videos on rank 0, None elsewhere."""
         return [self.model.decode_pipelined(u, group) for u in zs]
+
+    def decode_spatial(self, zs, group=None):
+        """multi-GPU decode, W bands (every rank computes its columns of every layer): same call contract as decode_pipelined."""
+        return [self.model.decode_spatial(u, group) for u in zs]

@@ -1602,10 +1602,31 @@ def test_vae_pipelined_one_gpu(world):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={world}',
                         '--master-addr', '127.0.0.1', '--master-port', str(29570 + world),
-                        os.path.join(root, 'tests', 'dist_vae_worker.py')], capture_output=True, text=True, timeout=600)
+                        os.path.join(root, 'tests', 'dist_vae_worker.py')], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, MOVIIGEN_VAE_TEST='pipeline'))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     for k in range(world):
         assert f'VAEPIPE_OK rank{k}/{world}' in r.stdout
+
+
+@pytest.mark.parametrize('world', [2, 4, 8])
+def test_vae_spatial_one_gpu(world):
+    """W-band multi-rank VAE decode (WanVAE.decode_spatial; SURVEY 8(e): spatial bands with one halo pixel per convolution, reference decode
+    vae.py:544-568 on rank 0 alone) == single-GPU decode, bit for bit, video on rank 0: 10 latent columns over 2 / 4 / 8 gloo ranks sharing
+    cuda:0 = bands of 5+5, 3+3+2+2 (W not divisible), 2+2+1+1+1+1+1+1 (one-column bands), the default and the one-frame chunk lists, and a
+    second geometry with 9 columns.  Halo exchange in front of every 3x3 convolution (caches keep their halos), k|v all-gather in the
+    per-frame attention block, rank 0 assembles."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={world}',
+                        '--master-addr', '127.0.0.1', '--master-port', str(29580 + world),
+                        os.path.join(root, 'tests', 'dist_vae_worker.py')], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, MOVIIGEN_VAE_TEST='spatial'))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    for k in range(world):
+        assert f'VAESPATIAL_OK rank{k}/{world}' in r.stdout
 
 
 @pytest.mark.parametrize('world', [2, 3, 4])

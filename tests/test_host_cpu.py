@@ -247,7 +247,7 @@ def test_collectives_have_one_test_transport_guard():
         assert "'gloo'" not in code and '"gloo"' not in code, fn       # (round 6: peer_copy's fallback vote went to collectives.control_reduce)
         assert '.cpu()' not in code, fn
     col = open(os.path.join(dist_dir, 'collectives.py')).read()
-    assert len(re.findall(r'if _test_transport\.staged\(', col)) == 7          # all_to_all, all_gather, broadcast, send, recv, ring_hop, rendezvous
+    assert len(re.findall(r'if _test_transport\.staged\(', col)) == 8          # all_to_all, all_gather, broadcast, send, recv, neighbor_exchange, ring_hop, rendezvous
     tt = open(os.path.join(dist_dir, '_test_transport.py')).read()
     assert 'def staged(t, group):' in tt and "t.is_cuda and dist.get_backend(group) == 'gloo'" in tt
 
