@@ -318,9 +318,11 @@ def main():
                     help="N > 1: DiT block weights sharded over ALL N ranks and all-gathered one block ahead (the reference's "
                          '--dit_fsdp, wan/text2video.py:107-108 -> shard_model); with the default layout on 8 GPUs this is BASELINE '
                          'configs[3]: cfg2 x ulysses_sp4 x fsdp8')
-    ap.add_argument('--vae-parallel', action='store_true',
-                    help='N > 1: the VAE decode of the sec/video tail as the layer-pipelined decode over all ranks '
-                         '(WanVAE.decode_pipelined) instead of rank 0 alone as in the reference (text2video.py:260-261)')
+    ap.add_argument('--vae-parallel', nargs='?', const='spatial', default=None, choices=['spatial', 'pipeline'],
+                    help='N > 1: the VAE decode of the sec/video tail over all ranks instead of rank 0 alone as in the reference '
+                         '(text2video.py:260-261): spatial (the default of the flag) = every rank decodes its band of image columns '
+                         '(WanVAE.decode_spatial: halo columns before each 3x3 conv, k|v all-gather in the attention block), pipeline = the layer '
+                         'pipeline (WanVAE.decode_pipelined)')
     ap.add_argument('--transport', default=None, choices=['auto', 'torch', 'rccl_direct', 'peer_copy'],
                     help='N > 1: transport of the Ulysses exchange — torch.distributed nccl (default), the C-ABI collectives on the '
                          "library's own RCCL communicator, or one-sided peer copies on the copy engines")
@@ -553,7 +555,7 @@ def main():
     # region: WanVAE.decode of a latent of this size on rank 0 (the reference decodes on rank 0 only) and, reported
     # separately, the two umT5-XXL prompt encodes.  Random-init weights of the shipped architectures.
     vae_s = t5_s = None
-    vae_pipe = args.vae_parallel and world > 1
+    vae_pipe = args.vae_parallel if world > 1 else None       # None | 'spatial' | 'pipeline'
     if (rank == 0 or vae_pipe) and not args.no_video_tail:
         import weights as Wt
         z = latent.clone()
@@ -562,12 +564,13 @@ def main():
         vae = wan.modules.WanVAE(state_dict=Wt.make_vae_params(96, 1), device=dev)
         vae.decode([z[:, :2, :16, :16].contiguous()])        # warm-up launch of every kernel (tiny latent)
         if vae_pipe:
-            # --vae-parallel: the layer-pipelined decode over all ranks (every rank passes the same latent: the scheduler
-            # state is replicated); timed between two barriers, video on rank 0
-            vae.decode_pipelined([z[:, :2, :16, :16].contiguous()])
+            # --vae-parallel: the decode over all ranks (every rank passes the same latent: the scheduler state is replicated);
+            # timed between two barriers, video on rank 0
+            multi = vae.decode_spatial if vae_pipe == 'spatial' else vae.decode_pipelined
+            multi([z[:, :2, :16, :16].contiguous()])
             fence()
             t1 = time.perf_counter()
-            video = vae.decode_pipelined([z])[0]
+            video = multi([z])[0]
             fence()
         else:
             torch.cuda.synchronize()
@@ -706,7 +709,9 @@ def main():
                                 'how': 'rank 0: timing events around every block all-gather on its comm stream (gather) and around every '
                                        'wait of the compute stream for a gathered block (exposed); hidden = 1 - exposed / gather'}
             if vae_s is not None:
-                line['vae_decode_layout'] = f'layer pipeline over {world} ranks (WanVAE.decode_pipelined)' if vae_pipe else 'rank 0 alone (reference text2video.py:260-261)'
+                line['vae_decode_layout'] = (f'W bands over {world} ranks (WanVAE.decode_spatial)' if vae_pipe == 'spatial' else
+                                             f'layer pipeline over {world} ranks (WanVAE.decode_pipelined)' if vae_pipe else
+                                             'rank 0 alone (reference text2video.py:260-261)')
             if overlap and overlap['collectives']:
                 per = 1.0 / args.steps
                 line['overlap'] = {'groups': sp_groups, 'exchange_ms_per_step': overlap['exchange_ms'] * per, 'exposed_ms_per_step': overlap['exposed_ms'] * per,

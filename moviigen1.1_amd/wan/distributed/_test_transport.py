@@ -15,8 +15,8 @@ class EmulatedGroup:
 
     def __init__(self, size, rank=0, name='emulated'):
         self.size, self.rank, self.name = int(size), int(rank), name
-        self.link_bytes = {'all_to_all': 0, 'all_gather': 0}      # bytes this rank would send over ONE of its P - 1 links
-        self.calls = {'all_to_all': 0, 'all_gather': 0}
+        self.link_bytes = {'all_to_all': 0, 'all_gather': 0, 'p2p': 0}      # bytes this rank would send over ONE of its P - 1 links (p2p: to one neighbour)
+        self.calls = {'all_to_all': 0, 'all_gather': 0, 'p2p': 0}
 
     def _count(self, kind, total_bytes):
         self.calls[kind] += 1
@@ -57,10 +57,16 @@ def broadcast(t, src, group):
 
 
 def send(x, dst, group):
+    if isinstance(group, EmulatedGroup):
+        group.calls['p2p'] += 1
+        group.link_bytes['p2p'] += x.numel() * x.element_size()
+        return
     dist.send(x.detach().cpu().contiguous(), dst, group=group)
 
 
 def recv(x, src, group):
+    if isinstance(group, EmulatedGroup):
+        return x                                                   # (contents unspecified: an emulated run is a timing run)
     h = torch.empty(x.shape, dtype=x.dtype)
     dist.recv(h, src, group=group)
     x.copy_(h)
@@ -85,6 +91,12 @@ class RingHop:
 
 
 def neighbor_exchange(sends, recvs, group):
+    if isinstance(group, EmulatedGroup):
+        for (t, _), (src, _) in zip(recvs, sends):                  # "the neighbour's" border = my own
+            t.copy_(src)
+        group.calls['p2p'] += 1
+        group.link_bytes['p2p'] += max((t.numel() * t.element_size() for t, _ in sends), default=0)      # the two directions use two links
+        return
     host_r = [torch.empty(t.shape, dtype=t.dtype) for t, _ in recvs]
     ops = [dist.P2POp(dist.isend, t.detach().cpu().contiguous(), r, group) for t, r in sends] + \
           [dist.P2POp(dist.irecv, h, r, group) for h, (_, r) in zip(host_r, recvs)]

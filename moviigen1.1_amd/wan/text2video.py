@@ -60,6 +60,8 @@ class WanT2V:
         self.model.to(self.device)
         self.cfgp = None
         self.vae_parallel = bool(vae_parallel) and dist.is_initialized() and dist.get_world_size() > 1
+        # vae_parallel: True / 'spatial' = every rank decodes its band of image columns (WanVAE.decode_spatial); 'pipeline' = the layer pipeline
+        self.vae_parallel_kind = vae_parallel if vae_parallel in ('spatial', 'pipeline') else 'spatial'
         # flag combinations are validated BEFORE any process group is created
         want_ring = bool(use_ring or (sp_degrees and sp_degrees[1] > 1))
         if cfg_parallel and want_ring:
@@ -181,8 +183,8 @@ class WanT2V:
                     torch.cuda.empty_cache()
                     offloaded = True
             def decode():
-                if self.vae_parallel:    # layer-pipelined decode over all ranks, video assembled on rank 0
-                    out = self.vae.decode_pipelined(x0)
+                if self.vae_parallel:    # multi-GPU decode over all ranks, video assembled on rank 0: W bands (default), or the layer pipeline
+                    out = self.vae.decode_pipelined(x0) if self.vae_parallel_kind == 'pipeline' else self.vae.decode_spatial(x0)
                     return out if self.rank == 0 else None
                 return self.vae.decode(x0) if self.rank == 0 else None
             retry = False

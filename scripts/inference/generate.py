@@ -64,7 +64,9 @@ FLAGS = [
     # this engine's additions
     ('--cfg_parallel', dict(action='store_true', default=False,
                             help='cond / uncond forwards on the two halves of an even number of ranks, Ulysses inside each half (not with --ring_size > 1).')),
-    ('--vae_parallel', dict(action='store_true', default=False, help='layer-pipelined VAE decode over all ranks.')),
+    ('--vae_parallel', dict(nargs='?', const='spatial', default=False, choices=['spatial', 'pipeline'],
+                            help='VAE decode over all ranks instead of rank 0 alone: spatial (default) = every rank decodes a band of image columns, '
+                                 'pipeline = the decoder layers cut into one segment per rank.')),
     ('--prompt_embeds', dict(type=str, default=None, help="torch file {'prompt','negative'} of umT5 embeddings, replaces the text encoder.")),
 ]
 

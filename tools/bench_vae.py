@@ -21,6 +21,11 @@ ap.add_argument('--chunk', type=int, default=1, help='latent frames per decoder 
 ap.add_argument('--mode', default='exact', choices=('exact', 'bf16x3'), help='bf16x3: the opt-in split-bf16 convolutions (not the reference arithmetic)')
 ap.add_argument('--tile', default='auto', help="voxels per workgroup of the wide exact convolutions: auto (by shape), 128, 256")
 ap.add_argument('--stages', action='store_true', help='also time every decoder stage (first chunk / steady chunk) and model the layer pipeline of decode_pipelined for 2 / 4 / 8 ranks')
+ap.add_argument('--bands', type=int, nargs='*', default=[], metavar='P',
+                help='EMULATION on this one GPU of ONE rank of the W-band decode over P ranks (WanVAE.decode_spatial on a loop-back process group: the real '
+                     "band width, halo columns, gather copies and kernel launches of an interior rank; the neighbours' data is its own): measured seconds of the "
+                     'rank + the bytes it would put on a link, priced at --link-gbps.  Lines are marked `invalid: emulation`')
+ap.add_argument('--link-gbps', type=float, default=45.0)
 ap.add_argument('--upconv', default='phases', choices=('phases', 'gather'), help="the convs behind a 2x upsample: four 2x2 phase convs / one 3x3 through the upsample")
 args = ap.parse_args()
 Wd, Hd = (int(v) for v in args.size.split('x'))
@@ -46,6 +51,32 @@ flops = (1065.8e12 if args.upconv == 'phases' else 1116.5e12) * (Wd * Hd * args.
 print(json.dumps({'metric': 'vae_decode_sec', 'value': dt, 'second_decode_sec': dt_warm, 'upconv': args.upconv, 'mode': args.mode, 'tile': args.tile, 'size': args.size, 'frames': args.frames, 'chunks': chunks[:3],
                   'tflops_fp32': flops / dt / 1e12, 'fp32_mfma_peak_tflops': 157.3, 'frac': flops / dt / 157.3e12,
                   'finite': bool(torch.isfinite(video).all().item()), 'peak_mem_gb': torch.cuda.max_memory_allocated() / 2**30}))
+
+if args.bands:
+    # one rank of P, emulated: what the W split costs a rank in kernels and copies (measured) and in link time (bytes / rate, not overlapped)
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    from emulate_rank import patch_dist
+    from wan.distributed._test_transport import EmulatedGroup
+    patch_dist()
+    for P in args.bands:
+        r = 1 if P > 2 else 0                                    # an interior rank (two neighbours) whenever there is one
+        grp = EmulatedGroup(P, r, f'vae bands {P}')
+        vae.model.decode_spatial(z[:, :2], group=grp)            # warm-up of the band-shaped launches
+        torch.cuda.synchronize()
+        grp.link_bytes = {k: 0 for k in grp.link_bytes}
+        t1 = time.perf_counter()
+        vae.model.decode_spatial(z, group=grp)
+        torch.cuda.synchronize()
+        sec = time.perf_counter() - t1
+        halo_b, gather_b = grp.link_bytes['p2p'], grp.link_bytes['all_gather']
+        band_video = 3 * args.frames * Hd * (Wd // P) * 4
+        # halos: per direction on its own link; the k|v all-gather: 1/P of the buffer to each peer, all links concurrently (EmulatedGroup counts per link);
+        # the band of the video: ranks 1..P-1 -> rank 0 on P - 1 links concurrently
+        link_s = (halo_b - (band_video if r else 0) + gather_b + band_video) / (args.link_gbps * 1e9)
+        print(json.dumps({'metric': 'vae_decode_band_rank_sec', 'invalid': 'emulation: one rank of P on a loop-back group, link time modelled',
+                          'ranks': P, 'emulated_rank': r, 'band_columns_latent': (Wd // 8) // P, 'rank_seconds_measured': sec,
+                          'link_bytes_per_link': {'halo_columns_and_video_band': halo_b, 'kv_all_gather': gather_b}, 'link_seconds_modelled_not_overlapped': link_s,
+                          'modelled_makespan_s': sec + link_s, 'single_gpu_s': dt_warm, 'modelled_efficiency': dt_warm / (P * (sec + link_s)), 'size': args.size, 'frames': args.frames}))
 
 if args.stages:
     # per-stage milliseconds (HIP events around every _run_stage call of one more decode), the cost per MAC of each kernel
