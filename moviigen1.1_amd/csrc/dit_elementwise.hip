@@ -169,6 +169,109 @@ __global__ __launch_bounds__(NT) void rmsnorm_rope_kernel(
     }
 }
 
+// Round 6: ONE WAVE PER ROW.  The kernel above gives a row to a 256-thread workgroup: two __syncthreads per row for the sum of squares, the
+// (cos, sin) row staged through LDS behind a third, and `weight[col + j]` re-read from L1 for every row (20 KB of fp32 weights per 10 KB
+// row): 3.2-4.3 TB/s at dim 5120.  Here a wave owns a row (dim <= 8192: <= 16 16-byte chunks per lane), the sum of
+// squares is a wave reduction, the norm weights of the lane's columns live in registers for all rows the wave walks, and — 512 % head_dim == 0
+// makes a lane's position inside its head the same for all its chunks — the lane loads its own 4 (cos, sin) pairs of the row's token straight
+// from the tables (L1 / L2 resident, 33 KB at 21 x 52 x 120).  A wave streams: 10 loads, one reduction, 10 stores per row, nothing shared.
+// (Writing the keys from here straight into the attention kernel's packed tile layout was built and measured: the scattered 16-byte stores make it
+// slower than this kernel + the k half of mg_pack_kv_bf16 — experiments/rmsnorm_rope_pack_k_scattered.hip, profiles/r06g_rowwise.log.)
+template <int MAXN>
+__global__ __launch_bounds__(NT) void rmsnorm_rope_wave_kernel(
+    const uint16_t* __restrict__ x, int64_t ldx, uint16_t* __restrict__ out, int64_t ldo, int64_t rows,
+    int dim, const float* __restrict__ weight, float eps, int head_dim, const float2* __restrict__ rope_cs,
+    int F, int H, int W, int64_t pos0, float out_scale) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nc = dim >> 3;
+    const int c = head_dim >> 1, c1 = c / 3, c0 = c - 2 * c1;
+    const float2* tab_f = rope_cs;
+    const float2* tab_h = rope_cs ? rope_cs + (int64_t)F * c0 : nullptr;
+    const float2* tab_w = rope_cs ? tab_h + (int64_t)H * c1 : nullptr;
+    const int64_t grid_tokens = (int64_t)F * H * W;
+    const int p0 = ((lane * 8) % head_dim) >> 1;            // first of the lane's 4 rotation pairs: the same for all its chunks (512 % head_dim == 0)
+    float wgt[MAXN][8];
+#pragma unroll
+    for (int i = 0; i < MAXN; ++i) {
+        const int ch = lane + 64 * i;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wgt[i][j] = ch < nc ? weight[ch * 8 + j] : 0.f;
+    }
+    for (int64_t row = (int64_t)blockIdx.x * (NT / 64) + wave; row < rows; row += (int64_t)gridDim.x * (NT / 64)) {
+        u32x4_t o[MAXN];
+        {
+            const u16x8_t* xr = (const u16x8_t*)(x + row * ldx);
+            u16x8_t u[MAXN];
+#pragma unroll
+            for (int i = 0; i < MAXN; ++i) {
+                const int ch = lane + 64 * i;
+                u[i] = ch < nc ? xr[ch] : (u16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
+            }
+            const int64_t tok = pos0 + row;
+            const bool do_rope = rope_cs != nullptr && tok < grid_tokens;
+            float2 cs[4] = {{1.f, 0.f}, {1.f, 0.f}, {1.f, 0.f}, {1.f, 0.f}};
+            if (do_rope) {
+                const int pf = (int)(tok / ((int64_t)H * W));
+                const int rem = (int)(tok - (int64_t)pf * H * W);
+                const int ph = rem / W, pw = rem - ph * W;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int p = p0 + j;
+                    cs[j] = p < c0 ? tab_f[(int64_t)pf * c0 + p] : (p < c0 + c1 ? tab_h[(int64_t)ph * c1 + (p - c0)] : tab_w[(int64_t)pw * c1 + (p - c0 - c1)]);
+                }
+            }
+            float ss = 0.f;
+#pragma unroll
+            for (int i = 0; i < MAXN; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float f = bf2f(u[i][j]);
+                    ss += f * f;
+                }
+            const float r = rsqrtf(wave_sum(ss) / (float)dim + eps);
+#pragma unroll
+            for (int i = 0; i < MAXN; ++i) {
+                float y[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) y[j] = round_bf(bf2f(u[i][j]) * r) * wgt[i][j];
+                if (do_rope) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float a = y[2 * j], b = y[2 * j + 1];
+                        y[2 * j] = a * cs[j].x - b * cs[j].y;
+                        y[2 * j + 1] = a * cs[j].y + b * cs[j].x;
+                    }
+                }
+                o[i][0] = pack_bf2(y[0] * out_scale, y[1] * out_scale);
+                o[i][1] = pack_bf2(y[2] * out_scale, y[3] * out_scale);
+                o[i][2] = pack_bf2(y[4] * out_scale, y[5] * out_scale);
+                o[i][3] = pack_bf2(y[6] * out_scale, y[7] * out_scale);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MAXN; ++i) {
+            const int ch = lane + 64 * i;
+            if (ch < nc) ((u32x4_t*)(out + row * ldo))[ch] = o[i];
+        }
+    }
+}
+
+static void launch_rmsnorm_rope_wave(const uint16_t* x, int64_t ldx, uint16_t* out, int64_t ldo, int64_t rows, int dim,
+                                     const float* weight, float eps, int head_dim, const float2* cs, int F, int H, int W, int64_t pos0,
+                                     float out_scale, hipStream_t st) {
+    const int nc = dim >> 3;
+    int64_t grid = (rows + 3) / 4;
+    if (grid > 2048) grid = 2048;                 // 8 workgroups per CU: every wave keeps its weights for ~rows / 8192 rows
+#define RRW(N) hipLaunchKernelGGL((rmsnorm_rope_wave_kernel<N>), dim3((unsigned)grid), dim3(NT), 0, st, x, ldx, out, ldo, rows, dim, \
+                                  weight, eps, head_dim, cs, F, H, W, pos0, out_scale)
+    if (nc <= 64) RRW(1);
+    else if (nc <= 256) RRW(4);
+    else if (nc <= 640) RRW(10);
+    else RRW(16);
+#undef RRW
+}
+
 extern "C" int mg_rmsnorm_rope_bf16(const uint16_t* x, int64_t ldx, uint16_t* out, int64_t ldo,
                                     int64_t rows, int dim, const float* weight, float eps, int head_dim,
                                     const float* rope_cs, int F, int H, int W, int64_t pos0, float out_scale,
@@ -181,6 +284,10 @@ extern "C" int mg_rmsnorm_rope_bf16(const uint16_t* x, int64_t ldx, uint16_t* ou
     if (rope_cs && (F <= 0 || H <= 0 || W <= 0 || head_dim > 256)) return MG_ERR_SHAPE;
     if (rows <= 0) return MG_OK;
     hipStream_t st = (hipStream_t)stream;
+    if (512 % head_dim == 0 && !(((uintptr_t)x | (uintptr_t)out) & 15)) {      // the wave-per-row kernel (every head_dim the model family uses)
+        launch_rmsnorm_rope_wave(x, ldx, out, ldo, rows, dim, weight, eps, head_dim, (const float2*)rope_cs, F, H, W, pos0, out_scale, st);
+        return mg_check_launch();
+    }
     const int grid = (int)(rows < 65536 * 4 ? rows : 65536 * 4);
     const int nc = dim >> 3;
     const float2* cs = (const float2*)rope_cs;
@@ -463,4 +570,4 @@ extern "C" int mg_gate_residual_f32(float* x, int64_t ldx, const uint16_t* y, in
 }
 
 extern "C" const char* mg_version(void) { return "moviigen_hip 3 gfx950"; }
-extern "C" int mg_abi_version(void) { return 9; }   // 9: mg_attn_fwd_bf16_hd128 / _lse / _prescaled take a caller-owned workspace (mg_attn_workspace_bytes(); the library no longer allocates or synchronises on a launch path); 8: the product library exports no kernel-selection switch and no profiling hook (they live in libmoviigen_hip_ab.so, -DMG_AB_BUILD; mg_*_set_variant return a status there); 7: the VAE arithmetic mode is an argument of mg_vae_conv_f32 / mg_vae_upconv_phases_f32 (mg_vae_set_mode is gone), mg_attn_w64_flag_counter counts into two words, mg_attn_fwd_bf16_hd128_prescaled gained reserve_cus; 6: + mg_vae_set_mode; 5: + mg_vae_upconv_fold_weights_f32 / mg_vae_upconv_phases_f32; 4: mg_rmsnorm_rope_bf16 gained out_scale, mg_pack_kv_bf16's K row order follows the 16x16x32 attention kernel, + mg_attn_fwd_bf16_hd128_prescaled
+extern "C" int mg_abi_version(void) { return 9; }   // 9: mg_attn_fwd_bf16_hd128 / _lse / _prescaled take a caller-owned workspace (mg_attn_workspace_bytes(); the library no longer allocates or synchronises on a launch path), + the W-band VAE entries mg_vae_conv_cols_f32 / mg_vae_upconv_phases_cols_f32 / mg_vae_attn_rows_f32; 8: the product library exports no kernel-selection switch and no profiling hook (they live in libmoviigen_hip_ab.so, -DMG_AB_BUILD; mg_*_set_variant return a status there); 7: the VAE arithmetic mode is an argument of mg_vae_conv_f32 / mg_vae_upconv_phases_f32 (mg_vae_set_mode is gone), mg_attn_w64_flag_counter counts into two words, mg_attn_fwd_bf16_hd128_prescaled gained reserve_cus; 6: + mg_vae_set_mode; 5: + mg_vae_upconv_fold_weights_f32 / mg_vae_upconv_phases_f32; 4: mg_rmsnorm_rope_bf16 gained out_scale, mg_pack_kv_bf16's K row order follows the 16x16x32 attention kernel, + mg_attn_fwd_bf16_hd128_prescaled

@@ -755,28 +755,40 @@ int main(int argc, char** argv) {
         double ms_sum = 0;
         long launches = 0;
         if (is_gemm) {
-            const int N = 5120, K = 5120;
+            // powerloop gemm <variant> <secs> [N] [K] [epilogue] [data]: data 1 = the A operand all zero (same instruction stream, no switching in the multipliers)
+            const int N = argc > 5 ? atoi(argv[5]) : 5120, K = argc > 6 ? atoi(argv[6]) : 5120;
+            const int epi = argc > 7 ? atoi(argv[7]) : MG_EPI_GATE_RESID_F32, data = argc > 8 ? atoi(argv[8]) : 0;
             Dev<uint16_t> dA((size_t)M * K), dW(randbf((size_t)N * K, 0.05f));
-            fill(dA.p, dA.n);
+            if (data) CK(hipMemset(dA.p, 0, dA.n * 2)); else fill(dA.p, dA.n);
             Dev<float> db(randf(N)), dg(randf(N)), of((size_t)M * N);
             CK(hipMemset(of.p, 0, of.n * 4));
             mg_gemm_set_variant(var);
             while (ms_sum < secs * 1e3) {
-                ms_sum += 20 * time_ms([&] { mg_gemm_bf16(dA.p, K, dW.p, K, db.p, M, N, K, MG_EPI_GATE_RESID_F32, of.p, N, dg.p, 0); }, 20);
+                ms_sum += 20 * time_ms([&] { mg_gemm_bf16(dA.p, K, dW.p, K, db.p, M, N, K, epi, of.p, N, dg.p, 0); }, 20);
                 launches += 20;
             }
-            printf("powerloop gemm variant %d: %ld launches, %.3f ms each = %.1f TFLOP/s\n", var, launches, ms_sum / launches,
+            printf("powerloop gemm variant %d N %d K %d epi %d data %d: %ld launches, %.3f ms each = %.1f TFLOP/s\n", var, N, K, epi, data, launches, ms_sum / launches,
                    2.0 * M * N * K / (ms_sum / launches * 1e-3) / 1e12);
         } else {
-            const int heads = 8;
+            // powerloop attn <debug flags> <secs> [heads] [data] [kernel]: debug flags as mg_attn_w64_debug (2 k = filler placement k, 16 = static partition);
+            // data 0 = random bf16 (what a real launch sees), 1 = all zero, 2 = the constant 0x3c3c (no operand bit ever toggles): the same instruction stream
+            // at a different switching activity — what the package-power limit costs; kernel 3 = the round-2 kernel (w64)
+            const int heads = argc > 5 ? atoi(argv[5]) : 8;
+            const int data = argc > 6 ? atoi(argv[6]) : 0;
+            if (argc > 7) mg_attn_set_variant(atoi(argv[7]));
+            mg_attn_w64_debug(var);
             const int64_t ld = heads * 128, npk = (int64_t)heads * ((M + 63) / 64) * 8192;
             Dev<uint16_t> dq((size_t)M * ld), dkp((size_t)npk), dvp((size_t)npk), dout((size_t)M * ld);
-            fill(dq.p, dq.n); fill(dkp.p, dkp.n); fill(dvp.p, dvp.n);
+            if (data == 0) { fill(dq.p, dq.n); fill(dkp.p, dkp.n); fill(dvp.p, dvp.n); }
+            else {
+                const int byte = data == 1 ? 0 : 0x3c;
+                CK(hipMemset(dq.p, byte, dq.n * 2)); CK(hipMemset(dkp.p, byte, dkp.n * 2)); CK(hipMemset(dvp.p, byte, dvp.n * 2));
+            }
             while (ms_sum < secs * 1e3) {
                 ms_sum += 4 * time_ms([&] { mg_attn_fwd_bf16_hd128_prescaled(dq.p, ld, dkp.p, dvp.p, dout.p, ld, nullptr, M, M, heads, 0, attn_ws(), 0); }, 4);
                 launches += 4;
             }
-            printf("powerloop attention: %ld launches, %.3f ms each = %.1f TFLOP/s\n", launches, ms_sum / launches,
+            printf("powerloop attention flags %d heads %d data %d: %ld launches, %.3f ms each = %.1f TFLOP/s\n", var, heads, data, launches, ms_sum / launches,
                    4.0 * M * M * 128 * heads / (ms_sum / launches * 1e-3) / 1e12);
         }
         return 0;
