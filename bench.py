@@ -528,7 +528,9 @@ def main():
         # the second layout of the same video on the same ranks, its own warm-up and K timed steps; the primary's model is released first
         lat_primary = R['latent']
         R['model']._ws = {}
-        R['model'] = None
+        R['model'] = R['cfgp'] = None
+        import gc
+        gc.collect()                          # (module graphs hold reference cycles: without this the first model's 28.6 GB stay allocated)
         torch.cuda.empty_cache()
         R2 = measure(secondary, False)
         per = 1.0 / args.steps

@@ -57,14 +57,14 @@ MG_DEV float block_sum(float v, float* red) {
     return t;
 }
 
-// torch.nn.functional.gelu(x, approximate='tanh')
+// torch.nn.functional.gelu(x, approximate='tanh') = 0.5 x (1 + tanh(u)), u = sqrt(2/pi) (x + 0.044715 x^3).
+// With tanh(u) = 1 - 2 / (e^{2u} + 1):  0.5 x (1 + tanh(u)) = x / (1 + e^{-2u}) — ONE v_exp_f32 and ONE v_rcp_f32 per value (7 VALU instructions; the
+// round-1 form went through an IEEE division: ~22, and the GELU epilogue of ffn.0 is VALU-bound behind the tile's last MFMA: 0.72 VALU instructions per
+// MFMA over the launch, profiles/r06_pmc_gemm_v12.txt).  -2 log2(e) is folded into the polynomial's constants; x -> +inf: e -> 0, x; x -> -inf: e -> inf, -0.
 MG_DEV float gelu_tanh(float x) {
-    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-    float u = k0 * (x + k1 * x * x * x);
-    // tanh(u) = 1 - 2/(exp(2u)+1)
-    float e = __expf(2.f * u);
-    float t = 1.f - 2.f / (e + 1.f);
-    return 0.5f * x * (1.f + t);
+    const float a0 = -2.f * 1.4426950408889634f * 0.7978845608028654f, a1 = a0 * 0.044715f;
+    const float e = __builtin_amdgcn_exp2f(x * (a0 + a1 * (x * x)));      // e^{-2u}
+    return x * __builtin_amdgcn_rcpf(1.f + e);
 }
 MG_DEV float silu(float x) { return x / (1.f + __expf(-x)); }
 
