@@ -76,6 +76,20 @@ got = m([lat], t=t, context=[ctx], seq_len=32)[0]
 xch = m._ws[next(iter(m._ws))]['xchg']
 assert xch.peer is not None and torch.equal(got, ref), (got - ref).abs().max().item()
 print('PEER_COPY_OK', flush=True)
+# ---- round 6: the control plane and the preflight on the RCCL backend (device tensors, not gloo's host tensors), the W-band VAE decode's
+# collectives at world size 1, and the peer-copy failure word after a forward ----------------------------------------------------------------
+from wan.distributed import collectives, preflight  # noqa: E402
+assert collectives.control_reduce(3, 'max', G, dev) == 3 and collectives.control_reduce(0, 'min', G, dev, dtype=torch.int32) == 0
+assert collectives.control_broadcast(7.5, 0, G, dev) == 7.5
+assert not xch.peer_failed() and not m._peer_transport_failed()
+rep = preflight.run(None, dev, probe_peer_copy=True, budget_s=30)
+assert rep['backend'] == 'nccl' and rep['rccl_ranks'] == 1 and rep['peer_access'] == [[True]] and not rep['errors'], rep
+assert preflight.parse(rep)['transport_recommended'] == 'torch' and rep['rank_devices'][0]['device'] == 0
+collectives.neighbor_exchange([], [], G)                                   # an edge rank with no neighbours: nothing to post
+vae = wan.modules.WanVAE(state_dict=W.make_vae_params(8, 1), device=dev)
+zv = W.randn((16, 3, 4, 6), 44)
+assert torch.equal(vae.decode_spatial([zv], G)[0], vae.decode([zv])[0])     # P = 1: the plain decode
+print('RCCL_CONTROL_PREFLIGHT_OK', flush=True)
 m.sp_force = False
 m = fsdp.shard_model(m, device_id=0)
 got = m([lat], t=t, context=[ctx], seq_len=32)[0]

@@ -1862,7 +1862,7 @@ def test_rccl_backend_single_rank():
     r = subprocess.run([sys.executable, os.path.join(root, 'tests', 'dist_rccl_worker.py')], capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    for tag in ('RCCL_COLLECTIVES_OK', 'RCCL_SP_BRANCH_OK', 'RCCL_DIRECT_OK', 'PEER_COPY_OK', 'RCCL_FSDP_OK'):
+    for tag in ('RCCL_COLLECTIVES_OK', 'RCCL_SP_BRANCH_OK', 'RCCL_DIRECT_OK', 'PEER_COPY_OK', 'RCCL_CONTROL_PREFLIGHT_OK', 'RCCL_FSDP_OK'):
         assert tag in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
