@@ -38,15 +38,20 @@ def _go_on(t0, budget_s, group, device):
     return int(collectives.control_broadcast(1 if time.perf_counter() - t0 < budget_s else 0, 0, group, device, dtype=torch.int32)) == 1
 
 
+def _sync(device):
+    if device.type == 'cuda':
+        torch.cuda.synchronize(device)
+
+
 def _timed_exchange(fn, device, group, repeats=3):
     """-> seconds per call: max over the ranks of the mean of `repeats` calls after one warm-up call."""
     fn()
-    torch.cuda.synchronize(device)
+    _sync(device)
     dist.barrier(group=group)
     t = time.perf_counter()
     for _ in range(repeats):
         fn()
-    torch.cuda.synchronize(device)
+    _sync(device)
     return float(collectives.control_reduce((time.perf_counter() - t) / repeats, 'max', group, device))
 
 
@@ -84,9 +89,12 @@ def run(group, device, probe_peer_copy=False, budget_s=60.0, probe_bytes=PROBE_B
 
     # ---- ranks ----------------------------------------------------------------------------------------------------------------
     try:
-        props = torch.cuda.get_device_properties(device)
-        mine = {'rank': r, 'host': socket.gethostname(), 'device': device.index, 'name': props.name, 'uuid': str(getattr(props, 'uuid', '')),
-                'visible': torch.cuda.device_count(), 'ipc_mode_legacy': os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}
+        if device.type == 'cuda':
+            props = torch.cuda.get_device_properties(device)
+            mine = {'rank': r, 'host': socket.gethostname(), 'device': device.index, 'name': props.name, 'uuid': str(getattr(props, 'uuid', '')),
+                    'visible': torch.cuda.device_count(), 'ipc_mode_legacy': os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}
+        else:       # host tensors (the CPU tests of this file's logic): no device to describe, no peer access to ask for
+            mine = {'rank': r, 'host': socket.gethostname(), 'name': 'cpu'}
     except Exception as e:      # noqa: BLE001
         mine = {'rank': r, 'error': f'{type(e).__name__}: {e}'}
     try:

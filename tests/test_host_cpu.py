@@ -157,6 +157,36 @@ def test_scheduler_host_logic_vs_reference(golden, name, n, shift):
         assert ((lat - ref).abs().max() / ref.abs().max()).item() < 5e-6, (name, i)
 
 
+def test_preflight_report_logic():
+    """wan/distributed/preflight.py: what bench.py copies into its line from a report, and when the copy-engine transport is recommended —
+    only if its windows opened, its self-check raised nothing and it moved the probe >= 5 % faster than the collective."""
+    from wan.distributed import preflight
+    base = {'rccl_ranks': 8, 'peer_access': [[True] * 8] * 8, 'elapsed_s': 3.2, 'errors': [], 'ipc_open': True,
+            'link_gbps_measured': {'all_to_all': 40.0, 'peer_copy': 44.0}}
+    assert preflight.recommend(base) == 'peer_copy'
+    assert preflight.recommend({**base, 'link_gbps_measured': {'all_to_all': 40.0, 'peer_copy': 41.0}}) == 'torch'          # < 5 %
+    assert preflight.recommend({**base, 'ipc_open': False}) == 'torch' and preflight.recommend({**base, 'ipc_open': None}) == 'torch'
+    assert preflight.recommend({**base, 'errors': ['peer_copy: the probe pattern did not arrive intact']}) == 'torch'
+    assert preflight.recommend({**base, 'link_gbps_measured': {'all_to_all': 40.0}}) == 'torch'
+    assert preflight.recommend({'errors': ['preflight: RuntimeError: x']}) == 'torch'
+    p = preflight.parse({**base, 'recommended': preflight.recommend(base)})
+    assert p == {'rccl_ranks': 8, 'transport_recommended': 'peer_copy', 'link_gbps_measured': {'all_to_all': 40.0, 'peer_copy': 44.0},
+                 'peer_access_all': True, 'ipc_open': True, 'preflight_s': 3.2, 'preflight_errors': []}
+    row = [True, None, False] + [True] * 5            # None = a peer on another host / not visible: not counted; False = no access
+    assert preflight.parse({**base, 'peer_access': [row] + [[True] * 8] * 7})['peer_access_all'] is False
+    assert preflight.parse({})['transport_recommended'] == 'torch' and preflight.parse({})['peer_access_all'] is None
+
+
+def test_preflight_gloo_world2():
+    """the preflight end to end on 2 gloo ranks with host tensors (tests/dist_preflight_worker.py): stages, the time box decided by rank 0 for
+    the whole group, the report; the control-plane reductions and the copy-engine transport's all-or-none vote."""
+    script = os.path.join(ROOT, 'tests', 'dist_preflight_worker.py')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+                        '--master-port', '29547', script], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert 'PREFLIGHT_OK rank0/2' in r.stdout and 'PREFLIGHT_OK rank1/2' in r.stdout
+
+
 def test_unsupported_solver_config_raises():
     from wan.utils import FlowUniPCMultistepScheduler
     with pytest.raises(NotImplementedError):
