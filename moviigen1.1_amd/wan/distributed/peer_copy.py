@@ -72,36 +72,50 @@ def self_check(win, group, buffer_indices=None):
     P x PROBE_ELEMS elements per buffer and restores them; no full-size temporaries.  -> win or None"""
     import logging
     ok = 1
-    try:
-        P, r = win.P, win.rank
-        if buffer_indices is None:
-            buffer_indices = sorted({0, len(win.local) // 2})
-        for bi in buffer_indices:
-            mine = win.local[bi].view(P, -1)
-            n = min(PROBE_ELEMS, mine.shape[1])
-            keep = mine[:, :n].clone()
-            win._rendezvous()                                    # every rank saved its slots
-            error = None
-            try:
-                for k in range(P):
-                    p = (r + k) % P
-                    src = torch.full((n,), float((7 * r + p) % 251), dtype=mine.dtype, device=mine.device)
-                    win.views[bi][p].view(P, -1)[r, :n].copy_(src, non_blocking=True)
-            except Exception as e:      # noqa: BLE001 — refused here: the peers must still find this rank in the rendezvous
-                error = e
-            win._rendezvous()                                    # all writes have landed everywhere
-            if error is not None:
-                logging.warning(f'peer-copy transport: a copy of the self-check was refused on rank {r} ({type(error).__name__}: {error})')
-                ok = 0
-            else:
-                for s_ in range(P):                              # per slot, in the buffer's own dtype
-                    val = torch.tensor(float((7 * s_ + r) % 251), dtype=mine.dtype, device=mine.device)
-                    if not bool((mine[s_, :n] == val).all()):
-                        ok = 0
-            mine[:, :n].copy_(keep)
-    except Exception as e:      # noqa: BLE001
-        logging.warning(f'peer-copy transport: the self-check failed on rank {getattr(win, "rank", "?")} ({type(e).__name__}: {e})')
-        ok = 0
+    P, r = win.P, win.rank
+    if buffer_indices is None:
+        buffer_indices = sorted({0, len(win.local) // 2})
+
+    def guarded(what, fn):
+        """one local step; an exception makes this rank vote no but NEVER skips a rendezvous: every rank performs the same sequence of
+        collectives (two rendezvous per probed buffer, then the vote), whatever fails in between"""
+        nonlocal ok
+        try:
+            return fn()
+        except Exception as e:      # noqa: BLE001
+            logging.warning(f'peer-copy transport: self-check step "{what}" failed on rank {r} ({type(e).__name__}: {e})')
+            ok = 0
+            return None
+    for bi in buffer_indices:
+        st = {}
+
+        def save():
+            st['mine'] = win.local[bi].view(P, -1)
+            st['n'] = min(PROBE_ELEMS, st['mine'].shape[1])
+            st['keep'] = st['mine'][:, :st['n']].clone()
+
+        def write():
+            mine, n = st['mine'], st['n']
+            for k in range(P):
+                p = (r + k) % P
+                src = torch.full((n,), float((7 * r + p) % 251), dtype=mine.dtype, device=mine.device)
+                win.views[bi][p].view(P, -1)[r, :n].copy_(src, non_blocking=True)
+
+        def compare_and_restore():
+            nonlocal ok
+            mine, n = st['mine'], st['n']
+            for s_ in range(P):                                  # per slot, in the buffer's own dtype
+                val = torch.tensor(float((7 * s_ + r) % 251), dtype=mine.dtype, device=mine.device)
+                if not bool((mine[s_, :n] == val).all()):
+                    ok = 0
+            mine[:, :n].copy_(st['keep'])
+        guarded('save the probed elements', save)
+        win._rendezvous()                                        # every rank saved its slots
+        if 'keep' in st:
+            guarded('write the pattern into the peers', write)
+        win._rendezvous()                                        # all writes have landed everywhere
+        if 'keep' in st:
+            guarded('compare and restore', compare_and_restore)
     try:
         agreed = _vote(ok, win.group, win.local[0].device)
     except Exception as e:      # noqa: BLE001 — the control plane itself failed: nothing to fall back with, but say what happened

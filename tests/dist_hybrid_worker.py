@@ -111,6 +111,19 @@ if os.environ.get('MOVIIGEN_SP_TRANSPORT') == 'peer_copy' and cp is None and m.s
     assert x.peer is None and not m._peer_transport_failed()
     u = m([lat], t=ts[0], context=[ctx_null], seq_len=L)[0]
     assert torch.equal(u, refs[0][1])
+    # ... and BEFORE the first exchange: a copy refused inside the self-check on one rank, and a mapping that reaches the wrong memory on
+    # another — the vote says no on every rank, nobody waits in a rendezvous the failing rank skipped
+    from wan.distributed import peer_copy
+    bufs = [torch.zeros(world, 64, 48, dtype=torch.bfloat16, device=dev) for _ in range(2)]
+    win = peer_copy.PeerWindows(None, bufs)
+    assert peer_copy.self_check(win, dist.group.WORLD) is win and all(int(b.count_nonzero()) == 0 for b in bufs)      # intact: passes, buffers restored
+    if rank == world - 1:
+        win.views[1][0] = Refused()
+    assert peer_copy.self_check(win, dist.group.WORLD) is None
+    win2 = peer_copy.PeerWindows(None, bufs)
+    if rank == 0 and world > 1:
+        win2.views[0][1] = torch.zeros_like(bufs[0])             # "rank 1's buffer" as mapped on rank 0 is some other memory
+    assert peer_copy.self_check(win2, dist.group.WORLD) is None
     print(f'PEER_FALLBACK_OK rank{rank}/{world}', flush=True)
 torch.cuda.synchronize()
 print(f'HYBRID_OK {mode} {backend} rank{rank}/{world}', flush=True)
