@@ -48,13 +48,16 @@ def cache_video(tensor, save_file=None, fps=30, suffix='.mp4', nrow=8, normalize
             try:
                 from .mp4_mjpeg import write_mp4_mjpeg
                 write_mp4_mjpeg(cache_file, frames, fps=fps)
-                logging.info(f'cache_video: imageio is not installed, wrote {frames.shape[0]} JPEG frames into {cache_file} (mp4v / Motion-JPEG, not H.264)')
+                logging.warning(f'cache_video: imageio is not installed, wrote {frames.shape[0]} JPEG frames into {cache_file} — an mp4v / Motion-JPEG '
+                                'track, NOT H.264: browsers and QuickTime will not play it (ffmpeg / VLC do)')
                 return cache_file
             except ModuleNotFoundError:          # no PIL either
                 pass
+            except Exception as e:               # noqa: BLE001 — an encode / IO error of the fallback writer must not lose the frames
+                logging.warning(f'cache_video: the Motion-JPEG fallback writer failed ({type(e).__name__}: {e}); writing the frames as .npy')
         path = osp.splitext(cache_file)[0] + '.npy'
         np.save(path, frames)
-        logging.info(f'cache_video: neither imageio nor PIL is installed, wrote the uint8 frames {frames.shape} to {path}')
+        logging.info(f'cache_video: no video writer available, wrote the uint8 frames {frames.shape} to {path}')
         return path
     error = None
     for _ in range(retry):
