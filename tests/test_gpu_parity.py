@@ -1492,6 +1492,31 @@ def test_rccl_multi_gpu(layout, transport):
     _run_hybrid(world, 'nccl', layout, 29630 + world + {'torch': 0, 'rccl_direct': 20, 'peer_copy': 40, 'auto': 60}[transport], transport)
 
 
+def test_emulation_tools_run():
+    """the two one-GPU emulations DESIGN 4 quotes — `tools/emulate_rank.py` (one rank of a P-GPU DiT step on loop-back groups) and
+    `tools/bench_vae.py --bands` (one rank of the W-band VAE decode) — still run against the engine as it is (small sizes: 2 layers, 720p;
+    a 256 x 256 x 9f decode) and mark their lines as emulation."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'emulate_rank.py'), '--workload', '720p', '--layers', '2', '--ranks', '2', '8',
+                        '--fsdp-at'], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith('{')]
+    em = [ln for ln in lines if 'invalid' in ln]
+    assert {(ln['ranks'], ln['layout']) for ln in em} == {(2, 'ulysses_sp2'), (2, 'cfg2 x ulysses_sp1'), (8, 'ulysses_sp8'), (8, 'cfg2 x ulysses_sp4')}
+    assert all(ln['compute_s_per_step'] > 0 and 'emulation' in ln['invalid'] for ln in em)
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'bench_vae.py'), '--size', '256x256', '--frames', '9', '--chunk', '4', '--bands', '2', '4'],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith('{')]
+    bands = [ln for ln in lines if ln.get('metric') == 'vae_decode_band_rank_sec']
+    assert [ln['ranks'] for ln in bands] == [2, 4] and all('emulation' in ln['invalid'] and ln['rank_seconds_measured'] > 0 for ln in bands)
+    assert bands[1]['band_columns_latent'] == 8 and bands[1]['link_bytes_per_link']['kv_all_gather'] > 0
+
+
 def test_train_side_sp_forward_one_gpu():
     """SURVEY 8(f) rank 4, second half: the training-side sequence-parallel DiT forward (reference
     scripts/train/model/model_seq.py) on the engine, 2 gloo ranks on cuda:0, vs the reference-generated golden g8
