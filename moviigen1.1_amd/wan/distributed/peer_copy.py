@@ -116,6 +116,10 @@ def self_check(win, group, buffer_indices=None):
         win._rendezvous()                                        # all writes have landed everywhere
         if 'keep' in st:
             guarded('compare and restore', compare_and_restore)
+    # the restores above are asynchronous copies on THIS stream; the exchanges that follow run on another one (HeadExchange.comm) and a peer's
+    # first real copy may land as soon as the vote lets it go: the restore must be complete before this rank votes (it was the vote's own
+    # device-to-host copy that ordered this in round 5; found as a once-in-a-dozen-runs wrong answer of the 8-rank one-GPU test)
+    guarded('wait for the restores', lambda: torch.cuda.current_stream(win.local[0].device).synchronize())
     try:
         agreed = _vote(ok, win.group, win.local[0].device)
     except Exception as e:      # noqa: BLE001 — the control plane itself failed: nothing to fall back with, but say what happened
