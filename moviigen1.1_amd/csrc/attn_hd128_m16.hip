@@ -413,11 +413,14 @@ __global__ __launch_bounds__(M16_THREADS, 1) void attn_hd128_m16_kernel(
         item_step = nwg >> 3;           // host guarantees nwg % 8 == 0 here
     }
     unsigned next_ticket = 0;
+    unsigned long long ph[7] = {0, 0, 0, 0, 0, 0, 0}, ph_t = 0;      // PROF: per-item phases (wave 0): {Q loads + first K / V tiles landed, first tile's S / reference / softmax / step 1, wait for the refills, steady loop, drain, epilogue, items}
+    unsigned long long pf_fence = 0, pf_a = 0, pf_b = 0, pf_n = 0;      // PROF: the steady loop's per-tile parts, summed over the items (stored once, at the end: an atomic per item would sit in the drain's vmcnt wait)
     while (item < item_end) {
     if (ticketed && tid == 0) next_ticket = atomicAdd(tickets, 1u);      // the item after this one; the answer has 2.8 ms to arrive
     const int head = item / nqb;
     const int qb0 = item - head * nqb;
     __syncthreads();                    // the previous item's last LDS reads are done before this one's DMA
+    if (PROF) ph_t = __builtin_amdgcn_s_memtime();
 
     // Q fragments (B operand): query block n of this wave = rows 64*wave + 16*n + qi, d = 32*c + 8*G .. +7
     bf16x8_t qf[4][4];
@@ -575,6 +578,7 @@ __global__ __launch_bounds__(M16_THREADS, 1) void attn_hd128_m16_kernel(
 #pragma unroll
         for (int n = 0; n < 4; ++n) dma_k(0, 0, n), dma_v(0, 0, n), dma_k(1, 1, n);
         fence();
+        if (PROF) { const unsigned long long tt = __builtin_amdgcn_s_memtime(); ph[0] += tt - ph_t; ph_t = tt; }
 #pragma unroll
         for (int n = 0; n < 4; ++n) dma_k(2, 2, n), dma_v(1, 1, n);     // iteration 0's refill
         bare_S(KB0{}, 0, 64);
@@ -599,7 +603,6 @@ __global__ __launch_bounds__(M16_THREADS, 1) void attn_hd128_m16_kernel(
         prefetch(k_addr(1, 0), v_addr(0, 0));
         m16_step<0, 1, true, true, SCALED, ORD>(s, qf, kf, vf, k_addr(1, 0), v_addr(0, 0), k_addr(1, 1), v_addr(0, 1), c_log2, M16NoDma());
         int t = 1;
-        unsigned long long pf_fence = 0, pf_a = 0, pf_b = 0, pf_n = 0;
         // ---- steady loop, with its state CARRIED instead of recomputed (round 5).  Per tile the loop used to spend ~35 instructions outside
         // MFMA gaps — slot indices -> eight LDS read addresses, two 64-bit global addresses with their clamps, M0 values — clumped at the top of
         // the tile and in front of the first K / V piece, each with the matrix pipe empty (one wave per SIMD).  Now:
@@ -632,8 +635,10 @@ __global__ __launch_bounds__(M16_THREADS, 1) void attn_hd128_m16_kernel(
         // The carried registers may be scratch reloads of the preheader: with no VMEM instruction of its own in the loop (the loads are opaque
         // asm) the compiler's wait-count pass would carry "reload pending" around the back edge and wait vmcnt(1) in front of a fragment read in
         // the MIDDLE of step A — i.e. for the refill loads just issued (measured: step A 1275 -> 2150 cycles).  A wait it can see, out here:
+        if (PROF) { const unsigned long long tt = __builtin_amdgcn_s_memtime(); ph[1] += tt - ph_t; ph_t = tt; }
         __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0)
         asm volatile("" : "+v"(ka0), "+v"(ka1), "+v"(ka2), "+v"(va0), "+v"(va1), "+v"(va2));
+        if (PROF) { const unsigned long long tt = __builtin_amdgcn_s_memtime(); ph[2] += tt - ph_t; ph_t = tt; }
         for (; t + 1 < nfull; ++t) {
             const unsigned long long c0 = PROF ? __builtin_amdgcn_s_memtime() : 0;
             fence_hot();                // K(t+1), V(t) visible; everyone is past iteration t-1
@@ -674,14 +679,9 @@ __global__ __launch_bounds__(M16_THREADS, 1) void attn_hd128_m16_kernel(
 #undef M16_BDMA0
 #undef M16_BDMAN
         asm volatile("s_mov_b32 m0, %0" :: "s"(keep_m0) : "memory");
+        if (PROF) { const unsigned long long tt = __builtin_amdgcn_s_memtime(); ph[3] += tt - ph_t; ph_t = tt; }
         static_assert(M16_TILE == 0x4000, "the literal above");
         const int s0 = (t - 1) % 3, s1 = t % 3, s2 = (t + 1) % 3;     // slots of tiles t-1, t, t+1 (tile i lives in slot i % 3)
-        if (PROF && prof && lane == 0) {
-            atomicAdd(prof + wave * 4 + 0, pf_fence);
-            atomicAdd(prof + wave * 4 + 1, pf_a);
-            atomicAdd(prof + wave * 4 + 2, pf_b);
-            atomicAdd(prof + wave * 4 + 3, pf_n);
-        }
         // here t == nfull - 1 (last full tile), S(t,0) is complete, P(t-1,1) is ready, ring primed for u = 2t
         fence();
         if (t + 1 < T) {                // a ragged tile t+1 follows: its V is staged now (slot s2)
@@ -720,6 +720,7 @@ __global__ __launch_bounds__(M16_THREADS, 1) void attn_hd128_m16_kernel(
             s.m_run[n] = -s.mq[n][0];       // what the lse below is relative to
         }
         const bool flagged = __syncthreads_or(s.bad) != 0;      // workgroup-uniform: the sweep and the exact loop have barriers
+        if (PROF) { const unsigned long long tt = __builtin_amdgcn_s_memtime(); ph[4] += tt - ph_t; ph_t = tt; }
         if (!flagged || (dbg & 1)) break;                       // (debug bit 0: keep the pipelined result even when flagged)
         if (flagcnt && tid == 0) atomicAdd(flagcnt + (attempt ? 1 : 0), 1u);   // debug hook: [0] blocks repeated, [1] blocks sent to the exact loop
         if (attempt) {                      // flagged with the true maxima as reference: inf / NaN scores
@@ -766,6 +767,7 @@ __global__ __launch_bounds__(M16_THREADS, 1) void attn_hd128_m16_kernel(
             }
         }
     }
+    if (PROF) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const unsigned long long tt = __builtin_amdgcn_s_memtime(); ph[5] += tt - ph_t; ph[6] += 1; }      // (PROF waits for the stores: what the next item's loads queue behind)
     if (ticketed) {
         if (tid == 0) s_next_item = nwg + (int)next_ticket;
         __syncthreads();
@@ -779,6 +781,16 @@ __global__ __launch_bounds__(M16_THREADS, 1) void attn_hd128_m16_kernel(
         __hip_atomic_store(tickets + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (PROF && prof && tid == 0) prof[16 + 2 * bid] = r_start, prof[16 + 2 * bid + 1] = __builtin_amdgcn_s_memrealtime();      // the last launch's {start, end} per workgroup
+    if (PROF && prof && lane == 0) {
+        atomicAdd(prof + wave * 4 + 0, pf_fence);
+        atomicAdd(prof + wave * 4 + 1, pf_a);
+        atomicAdd(prof + wave * 4 + 2, pf_b);
+        atomicAdd(prof + wave * 4 + 3, pf_n);
+    }
+    if (PROF && prof && tid == 0) {     // [1040 .. 1047): wave 0's per-item phases, summed over the workgroups and launches
+#pragma unroll
+        for (int i = 0; i < 7; ++i) atomicAdd(prof + 1040 + i, ph[i]);
+    }
 }
 
 // Ticket counters of the persistent launches: ONE pair {next ticket, workgroups done} in the CALLER's workspace (mg_attn_workspace_bytes()

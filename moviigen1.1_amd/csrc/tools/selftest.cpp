@@ -675,8 +675,8 @@ int main(int argc, char** argv) {
     }
     if (argc > 1 && !strcmp(argv[1], "w64prof")) {  // s_memtime breakdown of the w64 hot loop
         unsigned long long* buf;
-        CK(hipMalloc(&buf, (16 + 1024) * 8));
-        CK(hipMemset(buf, 0, (16 + 1024) * 8));
+        CK(hipMalloc(&buf, (16 + 1024 + 8) * 8));
+        CK(hipMemset(buf, 0, (16 + 1024 + 8) * 8));
         mg_attn_set_variant(argc > 4 ? atoi(argv[4]) : 0);
         mg_attn_w64_profile(buf);                // (both kernels share the hook)
         if (argc > 6) mg_attn_w64_debug(atoi(argv[6]));
@@ -706,6 +706,16 @@ int main(int argc, char** argv) {
                        (double)(t1 - t0) / 100.0, mean_end / nw, 100.0 * (1.0 - mean_end / nw / ((double)(t1 - t0) / 100.0)));
                 for (int x = 0; x < 8; ++x)
                     if (xn[x]) printf("  XCD %d: first end %.1f  mean end %.1f  last end %.1f us\n", x, xmin[x], xe[x] / xn[x], xmax[x]);
+            }
+        }
+        {   // m16: wave 0's per-item phases (s_memtime cycles), summed over workgroups and launches
+            unsigned long long ph[7];
+            CK(hipMemcpy(ph, buf + 1040, sizeof ph, hipMemcpyDeviceToHost));
+            if (ph[6]) {
+                const double n = (double)ph[6];
+                printf("per item (%.0f items), cycles: Q + first K / V tiles landed %.0f | first tile: S, reference, softmax, step 1 %.0f | wait for the refills %.0f | steady loop %.0f | "
+                       "drain + row sums %.0f | normalise + store O, stores drained %.0f | sum %.0f\n",
+                       n, ph[0] / n, ph[1] / n, ph[2] / n, ph[3] / n, ph[4] / n, ph[5] / n, (ph[0] + ph[1] + ph[2] + ph[3] + ph[4] + ph[5]) / n);
             }
         }
         mg_attn_w64_profile(nullptr);
