@@ -80,13 +80,13 @@ MG_DEV void m16_wait() {
 // S^T accumulators live in ARCH VGPRs (the softmax reads them with VALU instructions): inline asm with "v" operands,
 // as in w64.  A block is written by groups 0-3 (a) / 4-7 (b) of a step and first read by the NEXT step's softmax.
 MG_DEV void m16_mfma_s0(f32x4_t& acc, const bf16x8_t& a, const bf16x8_t& b, const f32x4_t& c) {       // acc = a.b + c
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=&v"(acc) : "v"(a), "v"(b), "v"(c));
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=&v"(acc) : "v"(a), "a"(b), "v"(c));
 }
 MG_DEV void m16_mfma_s(f32x4_t& acc, const bf16x8_t& a, const bf16x8_t& b) {        // acc += a.b
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b));
 }
 MG_DEV void m16_mfma_s_after_valu(f32x4_t& acc, const bf16x8_t& a, const bf16x8_t& b) {   // start value written by VALU (mask)
-    asm volatile("s_nop 7\n\ts_nop 7\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+    asm volatile("s_nop 7\n\ts_nop 7\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b));
 }
 constexpr int m16_koff(int i) { return (i >> 2) * 256 + (i & 3) * 4096; }   // K fragment i = (key block i>>2, d chunk i&3)
 constexpr int m16_voff(int i) { return i * 256; }                           // V fragment i = d block
@@ -467,10 +467,17 @@ __global__ __launch_bounds__(M16_THREADS, 1) void attn_hd128_m16_kernel(
         s.bad = 0;
     };
     reset();
+    // Q fragments live in the ACCUMULATOR half of the register file (MFMA B operands may be read from there; the VALU never touches them): the 64
+    // arch VGPRs this frees are what the register allocator needs to get into and out of the steady loop without swapping ~60 values through scratch
+    // (profiles/r06p_attn_q_agpr.log: "first tile" 19.6 -> 9.9 thousand cycles per item, the 512-key launch 3.10 -> 2.64 ms, the self-attention
+    // launch +0.3 %, same bits).  They are pinned there BEHIND the first K / V tiles' requests (q_pin, after the first fence of either pass): pinned
+    // here, the wave waited for its 16 Q loads before it asked for the tiles — two memory round trips in a row at the start of every item.
+    auto q_pin = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int n = 0; n < 4; ++n)
+        for (int n = 0; n < 4; ++n)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) asm volatile("" : "+v"(qf[n][c]));
+            for (int c = 0; c < 4; ++c) asm volatile("" : "+a"(qf[n][c]));
+    };
     auto fence = [&]() __attribute__((always_inline)) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -578,6 +585,7 @@ __global__ __launch_bounds__(M16_THREADS, 1) void attn_hd128_m16_kernel(
 #pragma unroll
         for (int n = 0; n < 4; ++n) dma_k(0, 0, n), dma_v(0, 0, n), dma_k(1, 1, n);
         fence();
+        q_pin();
         if (PROF) { const unsigned long long tt = __builtin_amdgcn_s_memtime(); ph[0] += tt - ph_t; ph_t = tt; }
 #pragma unroll
         for (int n = 0; n < 4; ++n) dma_k(2, 2, n), dma_v(1, 1, n);     // iteration 0's refill
@@ -739,6 +747,7 @@ __global__ __launch_bounds__(M16_THREADS, 1) void attn_hd128_m16_kernel(
 #pragma unroll
             for (int n = 0; n < 4; ++n) dma_k(t, 0, n), dma_v(t, 0, n);
             fence();
+            q_pin();
             const int lim = t == T - 1 ? last_lim : 64;
             bare_S(KB0{}, 0, lim);
             bare_S(KB1{}, 0, lim);
