@@ -351,6 +351,40 @@ MG_DEV void m16_step(M16State& s, const bf16x8_t (&qf)[4][4], bf16x8_t (&kf)[4],
             add_a(i, 1); add_b(i, 1); cvt(i, 1); M16_SB();
             P(i, 3); M16_SB();
             rdV(i); M16_SB(); dma(i); M16_SB();
+        } else if constexpr (ORD == 8) {          // placement 1's gaps, the MFMAs in PAIRS that share their A operand (S0 S1 P0 P1 S2 S3 P2 P3): an energy experiment
+            S(i, 0); M16_SB();
+            exp_a(i, 0); M16_SB();
+            S(i, 1); M16_SB();
+            exp_b(i, 0); M16_SB();
+            P(i, 0); M16_SB();
+            add_a(i, 0); add_b(i, 0); cvt(i, 0); M16_SB();
+            P(i, 1); M16_SB();
+            rdK(i); M16_SB(); rdV(i); M16_SB();
+            S(i, 2); M16_SB();
+            exp_a(i, 1); M16_SB();
+            S(i, 3); M16_SB();
+            exp_b(i, 1); M16_SB();
+            P(i, 2); M16_SB();
+            add_a(i, 1); add_b(i, 1); cvt(i, 1); M16_SB();
+            P(i, 3); M16_SB();
+            dma(i); M16_SB();
+        } else if constexpr (ORD == 9) {          // placement 1's gaps, the MFMAs in QUADS that share their A operand (S0 S1 S2 S3 P0 P1 P2 P3)
+            S(i, 0); M16_SB();
+            exp_a(i, 0); M16_SB();
+            S(i, 1); M16_SB();
+            exp_b(i, 0); M16_SB();
+            S(i, 2); M16_SB();
+            add_a(i, 0); add_b(i, 0); cvt(i, 0); M16_SB();
+            S(i, 3); M16_SB();
+            rdK(i); M16_SB(); rdV(i); M16_SB();
+            P(i, 0); M16_SB();
+            exp_a(i, 1); M16_SB();
+            P(i, 1); M16_SB();
+            exp_b(i, 1); M16_SB();
+            P(i, 2); M16_SB();
+            add_a(i, 1); add_b(i, 1); cvt(i, 1); M16_SB();
+            P(i, 3); M16_SB();
+            dma(i); M16_SB();
         } else {                                  // the four exps in four consecutive gaps:  [e][e][e][e][a a c][a a c][rK rV][dma]
             S(i, 0); M16_SB();
             exp_a(i, 0); M16_SB();
@@ -832,12 +866,20 @@ int mg_attn_m16_launch(const uint16_t* q, int64_t ldq, const uint16_t* kp, const
     unsigned* tickets = nullptr;
     if (workspace && (int64_t)total >= 32 * (int64_t)grid && !(g_m16_dbg & 16))      // (debug bit 4, A/B library: the static partition always)
         tickets = workspace;
-#define M16_ORD 1      // the filler placement the library ships (m16_step): one v_exp_f32 per MFMA gap, alone (profiles/r05m_attn_order.log: +4.8 % over placement 0)
+#define M16_ORD 9      // what the library ships (m16_step): one v_exp_f32 per MFMA gap, alone (placement 1, profiles/r05m_attn_order.log: +4.8 % over placement 0), and
+                       // the MFMAs of a group in quads that share their A operand (profiles/r06s_attn_mfma_order.log: +0.3 ... +0.5 % over S P S P, same cycles, same bits)
 #define M16_LAUNCH(PROF, SCALED, ORD)                                                                                             \
     hipLaunchKernelGGL((attn_hd128_m16_kernel<PROF, SCALED, ORD>), dim3(grid), dim3(M16_THREADS), 0, st, q, ldq, kp, vp, o, ldo, Lq, \
                        Lk, heads, prescaled ? 1.0f : c_log2, nqb, g_m16_dbg, PROF ? g_m16_prof : nullptr, lse, g_m16_flagcnt, tickets)
 #ifdef MG_AB_BUILD
     const int ord = (g_m16_dbg >> 1) & 7;     // measurement: mg_attn_w64_debug(2 * k) runs the pre-scaled entry on placement k
+    const int mo = (g_m16_dbg >> 5) & 3;      // measurement: debug bits 5-6 = MFMA order of a group (1: pairs, 2: quads sharing their A operand) under placement 1's gaps
+    if (mo && prescaled && !g_m16_prof) {
+        if (mo == 1) M16_LAUNCH(false, false, 8);
+        else if (mo == 2) M16_LAUNCH(false, false, 9);
+        else M16_LAUNCH(false, false, 1);     // 3: round 5's order (S P S P) under the same gaps
+        return mg_check_launch();
+    }
     if (ord && prescaled && !g_m16_prof) {
         if (ord == 1) M16_LAUNCH(false, false, 1);
         else if (ord == 2) M16_LAUNCH(false, false, 2);
