@@ -326,6 +326,8 @@ def main():
     ap.add_argument('--transport', default=None, choices=['auto', 'torch', 'rccl_direct', 'peer_copy'],
                     help='N > 1: transport of the Ulysses exchange — torch.distributed nccl (default), the C-ABI collectives on the '
                          "library's own RCCL communicator, or one-sided peer copies on the copy engines")
+    ap.add_argument('--no-shared-prefix-leg', action='store_true',
+                    help='skip the short leg after the timed region that measures the same step through WanModel.forward_pair (`shared_prefix`)')
     ap.add_argument('--no-pmc', action='store_true',
                     help="N = 1: skip the two rocprofv3 --pmc passes that measure the dominant kernel's HBM traffic after the timed "
                          'region (roofline.traffic is then read from the newest committed summary and labelled so)')
@@ -517,6 +519,36 @@ def main():
                 BlockShards.trace = None
         R['elapsed'] = elapsed
         R['latent'] = st['latent']
+        # ---- the same step through WanModel.forward_pair (what WanT2V.generate calls): everything in front of block 0's cross-attention is
+        # computed once for the two guidance branches.  Its own short leg AFTER the timed region — `value` stays the two plain forwards.
+        R['shared_prefix'] = None
+        k2 = min(args.steps, 2, 50 - total)
+        if cfgp is None and is_primary and k2 > 0 and not args.no_shared_prefix_leg:
+            def step_pair(i):
+                latent = st['latent']
+                t = ts[i:i + 1]
+                cond, uncond = model.forward_pair([latent], t, [ctx], [ctx_null], L)
+                ops.cfg_combine(noise_pred, uncond[0], cond[0], 5.0)
+                st['latent'] = sch.step(noise_pred.unsqueeze(0), ts_host[i], latent.unsqueeze(0), return_dict=False)[0].squeeze(0)
+            fence()
+            t1 = time.perf_counter()
+            for i in range(total, total + k2):
+                step_pair(i)
+            fence()
+            e2 = time.perf_counter() - t1
+            t = ts[total + k2 - 1:total + k2]
+            pc, pu = model.forward_pair([st['latent']], t, [ctx], [ctx_null], L)
+            same = torch.equal(pu[0], model([st['latent']], t=t, context=[ctx_null], seq_len=L)[0])
+            if world > 1:
+                tt = torch.tensor([e2, 0.0 if same else 1.0], device=dev, dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                e2, same = tt[0].item(), tt[1].item() == 0.0
+            R['shared_prefix'] = {'value': k2 / e2, 'ms_per_step': e2 / k2 * 1e3, 'steps': k2, 'second_branch_equals_plain_forward': same,
+                                  'what': 'the same step through WanModel.forward_pair (the call WanT2V.generate makes): patch / time embedding and block 0 up to '
+                                          'its self-attention residual read the latent and t only, so the second guidance branch starts from a copy of the '
+                                          'first one\'s residual stream there — one self-attention launch and four GEMMs of a step\'s 80 are not repeated; '
+                                          'bit-identical outputs (checked here on the last step, and by the GPU tests); NOT what `value` reports'}
+            del pc, pu
         assert torch.isfinite(R['latent']).all().item(), 'non-finite latent'
         R['parallelism'] = ('single' if world == 1 else f'cfg2 x ulysses_sp{R["sp"]}' if cfgp is not None else f'ulysses_sp{R["sp"]}') + \
                            (f' x fsdp{world}' if args.dit_fsdp and world > 1 else '')
@@ -632,6 +664,8 @@ def main():
                        'guide_scale': 5.0, 'weights': 'random N(0,0.02) bf16, seed 0',
                        **({'gemm_variant': args.gemm_variant} if args.gemm_variant else {})},
             'sec_per_video': (ms_step * 50 / 1e3 + vae_s) if vae_s is not None else None,
+            'shared_prefix': R['shared_prefix'],
+            'sec_per_video_shared_prefix': (R['shared_prefix']['ms_per_step'] * 50 / 1e3 + vae_s) if vae_s is not None and R['shared_prefix'] else None,
             'sec_per_video_parts': {'denoise_50_steps_s': ms_step * 50 / 1e3, 'vae_decode_s': vae_s,
                                     't5_encode_2_prompts_s_not_included': t5_s,
                                     'note': '50 x the measured step + the measured WanVAE.decode of this latent size, same '

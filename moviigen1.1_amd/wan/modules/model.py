@@ -541,7 +541,9 @@ class WanModel(nn.Module):
         ulysses.head_to_seq(ag, ws['a'], ug, U, N, hd)
 
     @torch.no_grad()
-    def _forward_one(self, lat, t, ctx, seq_len):
+    def _forward_one(self, lat, t, ctx, seq_len, share=None):
+        """share: None, or the two halves of forward_pair — 'save' keeps the residual stream as it stands behind block 0's self-attention
+        (ws['x0']), 'reuse' starts from that copy instead of recomputing it (same latent, same t: nothing before that point reads `ctx`)."""
         pk = self._pack()
         dev = lat.device
         lat = lat.to(torch.float32).contiguous()
@@ -571,16 +573,23 @@ class WanModel(nn.Module):
         ws = self._workspace(L, dev)
         x = ws['x']
 
+        reuse = share == 'reuse'
+        if share == 'save' and 'x0' not in ws:
+            ws['x0'] = torch.empty_like(x)
+        assert not reuse or 'x0' in ws, "share='reuse' follows a share='save' forward of the same latent and t"
+
         # patch embedding (model.py:529-531): bf16 result, residual stream kept in fp32 storage
-        if P == 1:
+        if reuse:
+            pass                                         # x comes back whole behind block 0's self-attention
+        elif P == 1:
             ops.patchify(lat, ph, pw, ws['tok'])
         else:
             full = torch.empty(Lfull, ws['tok'].shape[1], dtype=torch.bfloat16, device=dev)
             ops.patchify(lat, ph, pw, full)
             ws['tok'][:n_valid].copy_(full[pos0:pos0 + n_valid])  # torch.chunk(x, P, dim=1)[rank]
-        if n_valid:
+        if n_valid and not reuse:
             ops.gemm(ws['tok'][:n_valid], pk['patch_w'], self.patch_embedding.bias, ops.BIAS_F32, x[:n_valid])
-        if n_valid < L:
+        if n_valid < L and not reuse:
             x[n_valid:].zero_()                          # rows padded AFTER the patch embedding (no bias), :704-706
 
         # time embedding (model.py:541-545), fp32
@@ -603,17 +612,22 @@ class WanModel(nn.Module):
             lw = self._layer(i)
             m = mod[6 * i:6 * i + 6]
             # self attention
-            ops.ln_modulate(x, m[1], m[0], True, eps, ws['h'], round_norm_bf16=(i == 0))
-            custom = _replaced_forward(blk.self_attn)
-            if custom is None:
-                ops.gemm(ws['h'], lw['wqkv'], lw['bqkv'], ops.BIAS_BF16, ws['qkv'])
-                self._self_attention(ws, blk, grid, rope, L, pos0)
-                ops.gemm(ws['a'], lw['self_attn.o'], blk.self_attn.o.bias, ops.GATE_RESID_F32, x, gate=m[2])
+            if i == 0 and reuse:
+                x.copy_(ws['x0'])                        # block 0 up to here saw the latent and t only: the 'save' forward's stream, bit for bit
             else:
-                # operator seam (2) of the reference (text2video.py:97-100): the caller replaced
-                # block.self_attn.forward — call it with the reference's arguments and keep the fused rest
-                y = custom(ws['h'][None], torch.tensor([Lfull]), torch.tensor([list(grid)]), self.freqs)
-                ops.gate_residual(x, y[0].to(torch.bfloat16).contiguous(), m[2])
+                ops.ln_modulate(x, m[1], m[0], True, eps, ws['h'], round_norm_bf16=(i == 0))
+                custom = _replaced_forward(blk.self_attn)
+                if custom is None:
+                    ops.gemm(ws['h'], lw['wqkv'], lw['bqkv'], ops.BIAS_BF16, ws['qkv'])
+                    self._self_attention(ws, blk, grid, rope, L, pos0)
+                    ops.gemm(ws['a'], lw['self_attn.o'], blk.self_attn.o.bias, ops.GATE_RESID_F32, x, gate=m[2])
+                else:
+                    # operator seam (2) of the reference (text2video.py:97-100): the caller replaced
+                    # block.self_attn.forward — call it with the reference's arguments and keep the fused rest
+                    y = custom(ws['h'][None], torch.tensor([Lfull]), torch.tensor([list(grid)]), self.freqs)
+                    ops.gate_residual(x, y[0].to(torch.bfloat16).contiguous(), m[2])
+                if i == 0 and share == 'save':
+                    ws['x0'].copy_(x)
             # cross attention (text keys/values cached per prompt)
             ca = blk.cross_attn
             fa = _rebound_flash_attention()
@@ -664,6 +678,26 @@ class WanModel(nn.Module):
             outs = [self._forward_one(u, t[i if t.numel() > 1 else 0], c, seq_len)
                     for i, (u, c) in enumerate(zip(x, context))]
         return outs
+
+    def forward_pair(self, x, t, context, context_null, seq_len):
+        """The two guidance branches of ONE denoising step (reference text2video.py:237-240: two calls of the model on the same latent and t,
+        with the prompt's and the negative prompt's embeddings) -> (cond, uncond), each what forward() returns for its context, bit for bit.
+        Nothing in front of block 0's cross-attention reads the context — patch embedding, time embedding, and block 0's modulated LayerNorm,
+        q|k|v projection, RMS-norm + RoPE, self-attention over all L tokens and its gated residual see the latent and t only — so the second
+        branch starts from a copy of the first one's residual stream at that point (2.7 GB at 1920x832x81f) instead of computing it again:
+        one self-attention launch and four GEMMs of 80 per step.  A replaced self-attention forward or a rebound flash_attention (the operator
+        seams) may be anything, also non-deterministic: then, and with MOVIIGEN_CFG_SHARED_PREFIX=0, the branches run as two plain forwards."""
+        plain = os.environ.get('MOVIIGEN_CFG_SHARED_PREFIX', '1') == '0' or _rebound_flash_attention() is not None or \
+            _replaced_forward(self.blocks[0].self_attn) is not None or len(x) != 1 or len(context) != 1 or len(context_null) != 1
+        if plain:
+            return self.forward(x, t, context, seq_len), self.forward(x, t, context_null, seq_len)
+        t = t.reshape(-1)
+        for _ in range(2):
+            cond = self._forward_one(x[0], t[0], context[0], seq_len, share='save')
+            uncond = self._forward_one(x[0], t[0], context_null[0], seq_len, share='reuse')
+            if not self._peer_transport_failed():       # (see forward: a refused peer copy sends the whole group back to the collective, once)
+                break
+        return [cond], [uncond]
 
     def _peer_transport_failed(self):
         """once per forward (one 4-byte read per open window set — nothing at all on the default collective transport): did a peer copy

@@ -147,7 +147,13 @@ class WanT2V:
             noise_pred = torch.empty_like(latent)
             for i, t_host in enumerate(timesteps_host):
                 t = timesteps[i:i + 1]
-                if self.cfgp is None:
+                pair = getattr(self.model, 'forward_pair', None)
+                if self.cfgp is None and pair is not None:
+                    # both branches in one call: what they share (everything in front of block 0's cross-attention) is computed once,
+                    # the results are those of the two calls below bit for bit (WanModel.forward_pair)
+                    cond, uncond = pair([latent], t, context, context_null, seq_len)
+                    cond, uncond = cond[0], uncond[0]
+                elif self.cfgp is None:      # a model object without forward_pair: the reference's two calls (text2video.py:237-240)
                     cond = self.model([latent], t=t, context=context, seq_len=seq_len)[0]
                     uncond = self.model([latent], t=t, context=context_null, seq_len=seq_len)[0]
                 else:   # this half's branch only, then swap predictions with the partner rank

@@ -616,6 +616,41 @@ def test_dit_context_cache_and_determinism(dev):
     assert not torch.equal(a1, a3)
 
 
+def test_forward_pair_shares_block0_prefix_bit_equal(dev, monkeypatch):
+    """WanModel.forward_pair = the two guidance branches of a step (reference text2video.py:237-240) with everything in front of block 0's
+    cross-attention computed once: equal, bit for bit, to two plain forwards — in either order of the contexts, step after step (a stale
+    prefix of the previous latent / t would show), with padding rows (seq_len > L), and it skips the launches it says it skips."""
+    import wan
+    from wan.backend import ops
+    cfg = W.SMALL_DIT_HD128
+    m = wan.modules.WanModel(**cfg)
+    m.load_state_dict(W.make_dit_params(cfg, 0))
+    m.to(dev)
+    c1, c2 = W.randn((33, 128), 30).to(dev), W.randn((9, 128), 31).to(dev)
+    calls = {'attn': 0}
+    orig = ops.attention_hd128
+
+    def counting(*a, **k):
+        calls['attn'] += 1
+        return orig(*a, **k)
+    monkeypatch.setattr(ops, 'attention_hd128', counting)
+    for step, (tv, seed, seq_len) in enumerate([(700, 20, 48), (310, 21, 48), (310, 22, 64)]):
+        lat = W.randn((16, 2, 8, 12), seed).to(dev)
+        t = torch.tensor([tv], device=dev)
+        a = m([lat], t=t, context=[c1], seq_len=seq_len)[0].clone()
+        b = m([lat], t=t, context=[c2], seq_len=seq_len)[0].clone()
+        n0 = calls['attn']
+        pa, pb = m.forward_pair([lat], t, [c1], [c2], seq_len)
+        assert calls['attn'] - n0 == 4 * cfg['num_layers'] - 1, 'one self-attention launch fewer than two forwards'
+        assert torch.equal(pa[0], a) and torch.equal(pb[0], b), step
+        qb, qa = m.forward_pair([lat], t, [c2], [c1], seq_len)
+        assert torch.equal(qa[0], a) and torch.equal(qb[0], b), step
+    monkeypatch.setenv('MOVIIGEN_CFG_SHARED_PREFIX', '0')
+    n0 = calls['attn']
+    pa, pb = m.forward_pair([lat], t, [c1], [c2], seq_len)
+    assert calls['attn'] - n0 == 4 * cfg['num_layers'] and torch.equal(pa[0], a) and torch.equal(pb[0], b)
+
+
 # ------------------------------------------------------------------------------------------------
 # schedulers on the GPU (fused lincomb kernel) vs the reference trajectories
 # ------------------------------------------------------------------------------------------------
