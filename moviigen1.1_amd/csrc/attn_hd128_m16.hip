@@ -49,16 +49,6 @@
 typedef const __attribute__((address_space(1))) void* m16_gptr_t;
 typedef __attribute__((address_space(3))) void* m16_lptr_t;
 MG_DEV bf16x8_t m16_bf(u32x4_t v) { return __builtin_bit_cast(bf16x8_t, v); }
-// piece n of a wave's four consecutive 1 KiB pieces: the immediate offset advances the global AND the LDS address
-MG_DEV void m16_glds16_n(const void* g, void* l, int n) {
-    switch (n) {    // compile-time after unrolling; the builtin wants a literal
-        case 0: __builtin_amdgcn_global_load_lds((m16_gptr_t)g, (m16_lptr_t)l, 16, 0, 0); break;
-        case 1: __builtin_amdgcn_global_load_lds((m16_gptr_t)g, (m16_lptr_t)l, 16, 1024, 0); break;
-        case 2: __builtin_amdgcn_global_load_lds((m16_gptr_t)g, (m16_lptr_t)l, 16, 2048, 0); break;
-        default: __builtin_amdgcn_global_load_lds((m16_gptr_t)g, (m16_lptr_t)l, 16, 3072, 0); break;
-    }
-}
-
 struct M16State {
     f32x4_t ot[8][4];      // O^T [d block][query block]             (AGPRs: builtin MFMAs)
     f32x4_t st[2][2][4];   // S^T [unit kb][key block a/b][query block]  (arch VGPRs: inline-asm MFMAs)
@@ -413,6 +403,16 @@ MG_DEV void m16_step(M16State& s, const bf16x8_t (&qf)[4][4], bf16x8_t (&kf)[4],
     }
 }
 
+// the lane index, re-derived where it is called (two VALU instructions the compiler can neither hoist nor merge).  Everything that depends only on
+// the lane — LDS read bases, query rows, output addresses — is loop-invariant over the (head, query block) items AND over the tiles of an item: derived
+// from threadIdx once, the compiler computes all of it at kernel entry (43 registers), keeps it in scratch, and reloads it value by value, each behind
+// its own s_waitcnt vmcnt(0), at the start of an item, between the steps of the drain and in front of every output row (~45 round trips per item).
+MG_DEV int m16_lane() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
 struct M16NoDma {
     __device__ __forceinline__ void operator()(int) const {}
 };
@@ -428,7 +428,6 @@ __global__ __launch_bounds__(M16_THREADS, 1) void attn_hd128_m16_kernel(
     const unsigned long long r_start = PROF ? __builtin_amdgcn_s_memrealtime() : 0;     // the 100 MHz counter all workgroups share
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63, qi = lane & 15, G = lane >> 4;
     // persistent work loop over (head, query block) items, head-major.  Items are handed out by TICKET (`tickets` != nullptr): the first nwg
     // items by workgroup index, every further one by an atomic counter, fetched one item ahead.  The static partition it replaces for long launches — XCD x owns
     // items [x, x + 1) * total / 8 — lost 2.0 % of the metric's launch to its tail: the 32 workgroups of an XCD end within 2 us of each other,
@@ -453,6 +452,8 @@ __global__ __launch_bounds__(M16_THREADS, 1) void attn_hd128_m16_kernel(
     if (ticketed && tid == 0) next_ticket = atomicAdd(tickets, 1u);      // the item after this one; the answer has 2.8 ms to arrive
     const int head = item / nqb;
     const int qb0 = item - head * nqb;
+    const int lane = m16_lane();
+    int qi = lane & 15, G = lane >> 4;       // (re-derived behind the steady loop and in front of the output rows: m16_lane)
     __syncthreads();                    // the previous item's last LDS reads are done before this one's DMA
     if (PROF) ph_t = __builtin_amdgcn_s_memtime();
 
@@ -470,22 +471,34 @@ __global__ __launch_bounds__(M16_THREADS, 1) void attn_hd128_m16_kernel(
     const int T = (int)((Lk + 63) / 64);
     const int last_lim = (int)(Lk - (int64_t)(T - 1) * 64);     // keys in the last tile, 1..64
     // LDS-DMA: a tile is 16 pieces of 1 KiB; wave w moves pieces 4w..4w+3 of the K tile and of the V tile
-    const char* k_src = (const char*)(kp + ((int64_t)head * T) * 8192 + wave * 2048);   // wave-uniform (SGPRs)
-    const char* v_src = (const char*)(vp + ((int64_t)head * T) * 8192 + wave * 2048);
-    const unsigned lane_off = lane * 16;                                                  // the only per-lane part
     const int nfull = last_lim == 64 ? T : T - 1;
     // tile indices past the end are clamped (a redundant reload of the last tile into a free slot) instead of guarded
     const unsigned lds0 = (unsigned)(uintptr_t)(m16_lptr_t)smem;
-    auto dma_k = [&](int t, int slot, int n) __attribute__((always_inline)) {
-        const int tt = t < T ? t : T - 1;
-        m16_glds16_n(k_src + (int64_t)tt * 16384 + lane_off, smem + M16_K(slot) + wave * 4096, n);
+    // (round 6) EVERY LDS-DMA piece of the kernel is a buffer load behind the head's K / V resource: per-lane offset `dvo` (ONE register, the same for all
+    // pieces), the tile's byte offset a scalar, the LDS destination in M0, the pieces' 1 KiB steps in the instruction offset (global and LDS side alike).  The
+    // global_load_lds form this replaces outside the steady loop needed a 64-bit per-lane address per piece: the compiler hoisted those out of the item loop,
+    // spilled them, and reloaded them one by one — scratch_load, s_waitcnt vmcnt(0), load, 8 to 16 times in a row at the start of every item.
+    const uint64_t kb64 = (uint64_t)(uintptr_t)(kp + ((int64_t)head * T) * 8192), vb64 = (uint64_t)(uintptr_t)(vp + ((int64_t)head * T) * 8192);
+    const u32x4_t rs_k = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)kb64), (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(kb64 >> 32) & 0xffffu)),
+                          (unsigned)T * M16_TILE, 0x00020000u};
+    const u32x4_t rs_v = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)vb64), (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(vb64 >> 32) & 0xffffu)),
+                          (unsigned)T * M16_TILE, 0x00020000u};
+    const int dvo = wave * 4096 + lane * 16;      // this lane's 16 bytes of piece 0 inside a tile image
+    const unsigned lds_w = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + wave * 4096));      // this wave's piece 0 in K slot 0
+    // this wave's four pieces of tile t (clamped: a redundant reload of the last tile into a slot nobody reads) -> LDS at byte `lbase` (wave-uniform)
+    auto dma_tile4 = [&](const u32x4_t& rs, int t, unsigned lbase) __attribute__((always_inline)) {
+        const int soff = __builtin_amdgcn_readfirstlane((t < T ? t : T - 1) * M16_TILE);
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\t"      // (5 wait states: the resource / offset SGPRs may come straight from v_readfirstlane, and the loads are opaque to the hazard recognizer)
+                     "buffer_load_dwordx4 %0, %1, %3 offen lds\n\t"
+                     "buffer_load_dwordx4 %0, %1, %3 offen offset:1024 lds\n\t"
+                     "buffer_load_dwordx4 %0, %1, %3 offen offset:2048 lds\n\t"
+                     "buffer_load_dwordx4 %0, %1, %3 offen offset:3072 lds"
+                     :: "v"(dvo), "s"(rs), "s"(lbase), "s"(soff) : "memory");
     };
-    auto dma_v = [&](int t, int slot, int n) __attribute__((always_inline)) {
-        const int tt = t < T ? t : T - 1;
-        m16_glds16_n(v_src + (int64_t)tt * 16384 + lane_off, smem + M16_V(slot) + wave * 4096, n);
-    };
-    const unsigned kbase = lds0 + G * 1024 + qi * 16;                  // + M16_K(slot) + kb*512 + blk*256 + c*4096
-    const unsigned vbase = lds0 + 3 * M16_TILE + G * 2048 + qi * 16;   // + slot*TILE + kb*8192 + db*256
+    auto dma_k4 = [&](int t, int slot) __attribute__((always_inline)) { dma_tile4(rs_k, t, lds_w + M16_K(slot)); };
+    auto dma_v4 = [&](int t, int slot) __attribute__((always_inline)) { dma_tile4(rs_v, t, lds_w + M16_V(slot)); };
+    unsigned kbase = lds0 + G * 1024 + qi * 16;                  // + M16_K(slot) + kb*512 + blk*256 + c*4096
+    unsigned vbase = lds0 + 3 * M16_TILE + G * 2048 + qi * 16;   // + slot*TILE + kb*8192 + db*256
     auto k_addr = [&](int slot, int kb) __attribute__((always_inline)) { return kbase + slot * M16_TILE + kb * 512; };
     auto v_addr = [&](int slot, int kb) __attribute__((always_inline)) { return vbase + slot * M16_TILE + kb * 8192; };
 
@@ -593,14 +606,11 @@ __global__ __launch_bounds__(M16_THREADS, 1) void attn_hd128_m16_kernel(
             // are clamped: a redundant reload into a slot nobody reads), so a tile's DMA latency is covered by the S^T of
             // three others; vmcnt(12) = this wave's pieces of the OLDEST of the four tiles in flight have landed
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int n = 0; n < 4; ++n) dma_k(a, a, n);
+            for (int a = 0; a < 4; ++a) dma_k4(a, a);
             for (int t = 0; t < T; ++t) {
                 asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
                 __syncthreads();                // K(t) visible to all; everyone is past S(t-1): slot (t+4) % 6 = (t-2) % 6 is free
-#pragma unroll
-                for (int n = 0; n < 4; ++n) dma_k(t + 4, (t + 4) % 6, n);
+                dma_k4(t + 4, (t + 4) % 6);
                 const int lim = t == T - 1 ? last_lim : 64;
                 bare_S(KB0{}, t % 6, lim);
                 bare_S(KB1{}, t % 6, lim);
@@ -616,13 +626,11 @@ __global__ __launch_bounds__(M16_THREADS, 1) void attn_hd128_m16_kernel(
         // u = 2t+1 (S(t+1,0) | P.V(t,0) | softmax S(t,1)); tile t in slot t % 3.  Needs >= 3 FULL
         // tiles to have a steady state; shorter or all-ragged rows go straight to the exact loop.
         // ------------------------------------------------------------------------------------------
-#pragma unroll
-        for (int n = 0; n < 4; ++n) dma_k(0, 0, n), dma_v(0, 0, n), dma_k(1, 1, n);
+        dma_k4(0, 0), dma_v4(0, 0), dma_k4(1, 1);
         fence();
         q_pin();
         if (PROF) { const unsigned long long tt = __builtin_amdgcn_s_memtime(); ph[0] += tt - ph_t; ph_t = tt; }
-#pragma unroll
-        for (int n = 0; n < 4; ++n) dma_k(2, 2, n), dma_v(1, 1, n);     // iteration 0's refill
+        dma_k4(2, 2), dma_v4(1, 1);     // iteration 0's refill
         bare_S(KB0{}, 0, 64);
         bare_S(KB1{}, 0, 64);
         if (attempt == 0) {
@@ -641,6 +649,9 @@ __global__ __launch_bounds__(M16_THREADS, 1) void attn_hd128_m16_kernel(
 #pragma unroll
                 for (int n = 0; n < 4; ++n) s.st[kb][blk][n] += s.mq[n];
         m16_softmax_zero<0>(s, c_log2);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) asm volatile("" : "+v"(s.l_run[n]));     // summed HERE: left alone, the compiler sinks these 32 adds behind the steady loop (their
+        //                                                                      first use) and carries the 32 addends across it — through scratch
         // step u = 1: S(1,0) | P.V(0,0) | softmax S(0,1)
         prefetch(k_addr(1, 0), v_addr(0, 0));
         m16_step<0, 1, true, true, SCALED, ORD>(s, qf, kf, vf, k_addr(1, 0), v_addr(0, 0), k_addr(1, 1), v_addr(0, 1), c_log2, M16NoDma());
@@ -661,12 +672,6 @@ __global__ __launch_bounds__(M16_THREADS, 1) void attn_hd128_m16_kernel(
         unsigned lk0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + M16_K(0) + wave * 4096));      // this wave's piece 0 in those slots (K; V: + 3 tiles)
         unsigned lk1 = lk0 + M16_TILE, lk2 = lk0 + 2 * M16_TILE;
         int offk = (t + 2) * M16_TILE, offv = (t + 1) * M16_TILE;                 // byte offsets of tiles t+2 (K) / t+1 (V) in the head's image
-        const uint64_t kb64 = (uint64_t)(uintptr_t)(kp + ((int64_t)head * T) * 8192), vb64 = (uint64_t)(uintptr_t)(vp + ((int64_t)head * T) * 8192);
-        const u32x4_t rs_k = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)kb64), (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(kb64 >> 32) & 0xffffu)),
-                              (unsigned)T * M16_TILE, 0x00020000u};
-        const u32x4_t rs_v = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)vb64), (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(vb64 >> 32) & 0xffffu)),
-                              (unsigned)T * M16_TILE, 0x00020000u};
-        const int dvo = wave * 4096 + lane * 16;      // this lane's 16 bytes of piece 0 inside a tile image
         unsigned keep_m0, rot_tmp;
 #define M16_BDMA0(VOFF, RS, SOFF, LBASE, IMM)                                                                                              \
     asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %4 offen lds"                                             \
@@ -724,11 +729,16 @@ __global__ __launch_bounds__(M16_THREADS, 1) void attn_hd128_m16_kernel(
         if (PROF) { const unsigned long long tt = __builtin_amdgcn_s_memtime(); ph[3] += tt - ph_t; ph_t = tt; }
         static_assert(M16_TILE == 0x4000, "the literal above");
         const int s0 = (t - 1) % 3, s1 = t % 3, s2 = (t + 1) % 3;     // slots of tiles t-1, t, t+1 (tile i lives in slot i % 3)
+        {       // the drain's read bases and mask rows from a fresh lane index: nothing lane-derived lives across the steady loop
+            const int l2 = m16_lane();
+            qi = l2 & 15, G = l2 >> 4;
+            kbase = lds0 + G * 1024 + qi * 16;
+            vbase = lds0 + 3 * M16_TILE + G * 2048 + qi * 16;
+        }
         // here t == nfull - 1 (last full tile), S(t,0) is complete, P(t-1,1) is ready, ring primed for u = 2t
         fence();
         if (t + 1 < T) {                // a ragged tile t+1 follows: its V is staged now (slot s2)
-#pragma unroll
-            for (int n = 0; n < 4; ++n) dma_v(t + 1, s2, n);
+            dma_v4(t + 1, s2);
         }
         m16_step<1, 1, true, true, SCALED, ORD>(s, qf, kf, vf, k_addr(s1, 1), v_addr(s0, 1), k_addr(s2, 0), v_addr(s1, 0), c_log2, M16NoDma());
         if (t + 1 < T) {
@@ -778,8 +788,7 @@ __global__ __launch_bounds__(M16_THREADS, 1) void attn_hd128_m16_kernel(
         reset();
         for (int t = 0; t < T; ++t) {
             __syncthreads();
-#pragma unroll
-            for (int n = 0; n < 4; ++n) dma_k(t, 0, n), dma_v(t, 0, n);
+            dma_k4(t, 0), dma_v4(t, 0);
             fence();
             q_pin();
             const int lim = t == T - 1 ? last_lim : 64;
@@ -792,6 +801,10 @@ __global__ __launch_bounds__(M16_THREADS, 1) void attn_hd128_m16_kernel(
         }
     }
 
+    {
+        const int l3 = m16_lane();
+        qi = l3 & 15, G = l3 >> 4;
+    }
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
         float l_tot = s.l_run[n] + __shfl_xor(s.l_run[n], 16, 64);
@@ -824,7 +837,7 @@ __global__ __launch_bounds__(M16_THREADS, 1) void attn_hd128_m16_kernel(
         __hip_atomic_store(tickets + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (PROF && prof && tid == 0) prof[16 + 2 * bid] = r_start, prof[16 + 2 * bid + 1] = __builtin_amdgcn_s_memrealtime();      // the last launch's {start, end} per workgroup
-    if (PROF && prof && lane == 0) {
+    if (PROF && prof && (tid & 63) == 0) {
         atomicAdd(prof + wave * 4 + 0, pf_fence);
         atomicAdd(prof + wave * 4 + 1, pf_a);
         atomicAdd(prof + wave * 4 + 2, pf_b);
