@@ -25,6 +25,13 @@ extern unsigned long long* g_gemm5_prof;    // gemm_bf16.hip: mg_gemm5_debug_pro
 #endif
 
 // SCHED = which generated body (tools/gen_gemm_v12_schedule.py: SCHEDULES); chosen in the launcher
+// the lane index, re-derived where it is called: two VALU instructions the compiler can neither hoist out of the tile loop nor merge (see set_offsets)
+MG_DEV int v12_lane() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
 template <int EPI, int SCHED, bool PROF = false>
 __global__ __launch_bounds__(V11_THREADS, 1) void gemm_bf16_v12_kernel(
     const uint16_t* __restrict__ A, int64_t lda, const uint16_t* __restrict__ Wt, int64_t ldw,
@@ -55,8 +62,12 @@ __global__ __launch_bounds__(V11_THREADS, 1) void gemm_bf16_v12_kernel(
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, r16 = lane & 15, G = lane >> 4;
+    // FRESH: the lane index re-derived in front of each tile's offsets and epilogue (v12_lane).  Not for the fp32-store instantiation: with the registers that frees the
+    // allocator parks accumulators in scratch INSIDE the last k-tile (scratch_store of a[128:131] between MFMAs that reuse them) and the tile comes out wrong
+    // (test_gemm_epilogues[3-*], round 6) — that instantiation keeps the code it had (the DiT's fp32-store GEMM, the patch embedding, has K = 64: another kernel).
+    constexpr bool FRESH = EPI != MG_EPI_BIAS_F32;
+    const int lane0 = lane;
     const int wm = wave >> 1, wn = wave & 1;
-    const int srow = lane >> 3;
     constexpr int NP = 16;                       // LDS-DMA duty: wave w stages rows [64w, 64w+64) of A (pieces 0-7) and of W (8-15)
     const int prow0 = wave * 64;
 
@@ -72,14 +83,20 @@ __global__ __launch_bounds__(V11_THREADS, 1) void gemm_bf16_v12_kernel(
     int voff[NP];
     u32x4_t rs_a, rs_w;
     auto set_offsets = [&](int64_t m0, int n0) __attribute__((always_inline)) {
-        const int64_t rows_a = M - m0;
+        // (round 6) from a FRESH lane index, and the row clamp in 32 bits: the rows and chunks of the 16 pieces depend on the lane only, so derived from
+        // threadIdx the compiler computed them once at kernel entry (48 registers), kept them in scratch and reloaded them value by value — 26 to 30
+        // scratch_load / s_waitcnt vmcnt(0) pairs in a row at the top of EVERY tile, the matrix pipe empty
+        const int lane = FRESH ? v12_lane() : lane0;
+        const int srow = lane >> 3;
+        const int64_t rows_a64 = M - m0;
+        const int rows_a = rows_a64 < 0x40000000 ? (int)rows_a64 : 0x40000000;
         const int rows_w = N - n0;
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int row = prow0 + (i & 7) * 8 + srow;
             const int chunk = ((lane & 7) ^ ((row >> 1) & 7)) << 4;
             if (i < 8) {
-                const int r = row < rows_a ? row : (int)(rows_a - 1);
+                const int r = FRESH ? (row < rows_a ? row : rows_a - 1) : (row < rows_a64 ? row : (int)(rows_a64 - 1));
                 voff[i] = r * (int)(lda * 2) + chunk;
             } else {
                 const int f = PAIRED ? v11_feature_of_row(row) : row;
@@ -260,15 +277,16 @@ __global__ __launch_bounds__(V11_THREADS, 1) void gemm_bf16_v12_kernel(
         asm volatile("" :: "v"(touch[0]), "v"(touch[1]), "v"(touch[2]), "v"(touch[3]), "v"(touch[4]), "v"(touch[5]), "v"(touch[6]), "v"(touch[7]));
         V12_SB;
         if (PROF) { const unsigned long long tt = __builtin_amdgcn_s_memtime(); ps[1] += tt - tsg; tsg = tt; }
-        // ---- epilogue (gemm_v11_common.h) ----
+        // ---- epilogue (gemm_v11_common.h) ---- its row / column offsets from a fresh lane index (set_offsets: nothing lane-derived is carried across the k-loop in scratch)
+        const int lane_e = FRESH ? v12_lane() : lane0, r16_e = lane_e & 15, G_e = lane_e >> 4;
         if constexpr (PAIRED) {
 #ifdef MG_AB_BUILD
             if (flags & 1024)       // measurement: the tile's stores without the non-temporal hint
-                v11_epilogue_pair<EPI, false>(acc, m0 + wm * 128, n0 + wn * 128, r16, G, M, N, bias, out, ldo);
+                v11_epilogue_pair<EPI, false>(acc, m0 + wm * 128, n0 + wn * 128, r16_e, G_e, M, N, bias, out, ldo);
             else
 #endif
             // the tile is written once and read by another kernel: non-temporal stores (qkv +0.9 %, ffn.0 +1.6 %, N = 5120 unchanged: profiles/r05y4_gemm_pair_nt.log)
-            v11_epilogue_pair<EPI, true>(acc, m0 + wm * 128, n0 + wn * 128, r16, G, (flags & 4) ? 0 : M, N, bias, out, ldo);      // flags & 4: measurement without the stores
+            v11_epilogue_pair<EPI, true>(acc, m0 + wm * 128, n0 + wn * 128, r16_e, G_e, (flags & 4) ? 0 : M, N, bias, out, ldo);      // flags & 4: measurement without the stores
         }
         else {
             const int64_t m_wave = m0 + wm * 128;
@@ -276,26 +294,26 @@ __global__ __launch_bounds__(V11_THREADS, 1) void gemm_bf16_v12_kernel(
             if (!(flags & 16) && m_wave + 128 <= M && n_wave + 128 <= N)      // the wave's whole 128 x 128 block exists (wave-uniform)
             {
                 if (flags & 1)      // measurement: the round-4 form (each residual batch waited for with nothing else in flight)
-                    v11_epilogue_rows<EPI>(acc, smem + stage_last + wave * 16384, lane, r16, G, m_wave, n_wave, bias, gate, out, ldo);
+                    v11_epilogue_rows<EPI>(acc, smem + stage_last + wave * 16384, lane_e, r16_e, G_e, m_wave, n_wave, bias, gate, out, ldo);
 #ifdef MG_AB_BUILD
                 else if ((flags & 4) && (flags & 128))      // measurement: neither residual loads nor stores / no stores / no residual loads
-                    v11_epilogue_rows2<EPI, 3>(acc, smem + stage_last + wave * 16384, lane, r16, G, m_wave, n_wave, bias, gate, out, ldo);
+                    v11_epilogue_rows2<EPI, 3>(acc, smem + stage_last + wave * 16384, lane_e, r16_e, G_e, m_wave, n_wave, bias, gate, out, ldo);
                 else if (flags & 4)
-                    v11_epilogue_rows2<EPI, 2>(acc, smem + stage_last + wave * 16384, lane, r16, G, m_wave, n_wave, bias, gate, out, ldo);
+                    v11_epilogue_rows2<EPI, 2>(acc, smem + stage_last + wave * 16384, lane_e, r16_e, G_e, m_wave, n_wave, bias, gate, out, ldo);
                 else if (flags & 128)
-                    v11_epilogue_rows2<EPI, 1>(acc, smem + stage_last + wave * 16384, lane, r16, G, m_wave, n_wave, bias, gate, out, ldo);
+                    v11_epilogue_rows2<EPI, 1>(acc, smem + stage_last + wave * 16384, lane_e, r16_e, G_e, m_wave, n_wave, bias, gate, out, ldo);
                 else if ((flags & 256) && (flags & 512))      // no nt hint on the stores and the residual loads / the stores / the loads
-                    v11_epilogue_rows2<EPI, 12>(acc, smem + stage_last + wave * 16384, lane, r16, G, m_wave, n_wave, bias, gate, out, ldo);
+                    v11_epilogue_rows2<EPI, 12>(acc, smem + stage_last + wave * 16384, lane_e, r16_e, G_e, m_wave, n_wave, bias, gate, out, ldo);
                 else if (flags & 256)
-                    v11_epilogue_rows2<EPI, 4>(acc, smem + stage_last + wave * 16384, lane, r16, G, m_wave, n_wave, bias, gate, out, ldo);
+                    v11_epilogue_rows2<EPI, 4>(acc, smem + stage_last + wave * 16384, lane_e, r16_e, G_e, m_wave, n_wave, bias, gate, out, ldo);
                 else if (flags & 512)
-                    v11_epilogue_rows2<EPI, 8>(acc, smem + stage_last + wave * 16384, lane, r16, G, m_wave, n_wave, bias, gate, out, ldo);
+                    v11_epilogue_rows2<EPI, 8>(acc, smem + stage_last + wave * 16384, lane_e, r16_e, G_e, m_wave, n_wave, bias, gate, out, ldo);
 #endif
                 else
-                    v11_epilogue_rows2<EPI>(acc, smem + stage_last + wave * 16384, lane, r16, G, m_wave, n_wave, bias, gate, out, ldo);
+                    v11_epilogue_rows2<EPI>(acc, smem + stage_last + wave * 16384, lane_e, r16_e, G_e, m_wave, n_wave, bias, gate, out, ldo);
             }
             else
-                mg_gemm_epilogue16<EPI, 8, 8>(acc, m_wave, n_wave, r16, G, (flags & 4) ? 0 : M, N, bias, gate, out, ldo);
+                mg_gemm_epilogue16<EPI, 8, 8>(acc, m_wave, n_wave, r16_e, G_e, (flags & 4) ? 0 : M, N, bias, gate, out, ldo);
         }
         if (PROF) { const unsigned long long tt = __builtin_amdgcn_s_memtime(); ps[2] += tt - tsg; tsg = tt; }
         if (!has_next) {

@@ -244,6 +244,22 @@ def exit_pad(src, frag, skip, n_mfma):
     return out
 
 
+def accumulator_spills(src, frag, skip):
+    """no accumulator register goes to scratch: `scratch_store ... a[..]` anywhere in a kernel whose MFMAs are (partly) inline assembly.  Round 6: with 48 registers freed
+    in gemm_bf16_v12_kernel<fp32 store> the allocator parked a[128:131] in scratch between the MFMAs of the last k-tile that reuse them, and the tile came out wrong with
+    the hot block untouched (test_gemm_epilogues[3-*])."""
+    text = device_asm(src)
+    out = []
+    funcs = re.split(r'^(_Z\w+):', text, flags=re.M)
+    for name, body in zip(funcs[1::2], funcs[2::2]):
+        if frag not in name or re.search(skip, name):
+            continue
+        n = len(re.findall(r'scratch_store_dword\w*\s+off,\s*a\[?\d', body.split('.Lfunc_end')[0]))
+        if n:
+            out.append(f'{name[:60]}: {n} accumulator spill(s) to scratch')
+    return out
+
+
 def main():
     allp = []
     for k in KERNELS:
@@ -260,6 +276,9 @@ def main():
     pads = exit_pad('gemm_bf16_v12.hip', 'gemm_bf16_v12_kernel', r'kernelILi\dELi\dELb1E', 128)
     print(f'variant 12 exit pad: {"ok" if not pads else "VIOLATED"}')
     allp += pads
+    spills = accumulator_spills('gemm_bf16_v12.hip', 'gemm_bf16_v12_kernel', r'kernelILi\dELi\dELb1E')
+    print(f'variant 12 accumulator spills: {"none" if not spills else "FOUND"}')
+    allp += spills
     for p in allp:
         print('VIOLATION:', p)
     return 1 if allp else 0
