@@ -410,7 +410,7 @@ int mg_gemm_set_variant(int variant);
  * Returns MG_ERR_ARG for anything else. */
 int mg_attn_set_variant(int variant);
 
-void mg_attn_w64_profile(unsigned long long* dev_buf);     /* both attention kernels: 4 waves x {fence, step A, step B, iterations} at [0, 16); the m16 kernel also stores every workgroup's {start, end} (s_memrealtime) of the last launch at [16 + 2 b]: dev_buf holds 16 + 2 x 512 + 8 entries; m16 also adds wave 0's per-item phases {first loads landed, first tile, refill wait, steady loop, drain, epilogue, items} at [1040, 1047) */
+void mg_attn_w64_profile(unsigned long long* dev_buf);     /* both attention kernels: 4 waves x {fence, step A, step B, iterations} at [0, 16); the m16 kernel also stores every workgroup's {start, end} (s_memrealtime) of the last launch at [16 + 2 b]: dev_buf holds 16 + 2 x 512 + 8 entries; m16 also adds wave 0's per-item phases {first loads landed, first tile, refill wait, steady loop, drain, epilogue, items, epilogue up to its last store's issue} at [1040, 1048) */
 void mg_attn_w64_debug(int flags);                         /* bit 0: keep the pipelined result of flagged blocks (no exact pass) */
 void mg_attn_w64_flag_counter(unsigned* dev_counter);      /* dev_counter[2]: [0] += query blocks whose pipelined pass flagged (m16: repeated with swept row maxima; w64: redone by the exact loop), [1] += m16 blocks that went on to the exact loop */
 void mg_gemm_debug_profile(unsigned long long* dev_buf);   /* GEMM variants 1/2: 8 waves x {wait+barrier, stage issue, MFMA, k-tiles} */

@@ -446,7 +446,7 @@ __global__ __launch_bounds__(M16_THREADS, 1) void attn_hd128_m16_kernel(
         item_step = nwg >> 3;           // host guarantees nwg % 8 == 0 here
     }
     unsigned next_ticket = 0;
-    unsigned long long ph[7] = {0, 0, 0, 0, 0, 0, 0}, ph_t = 0;      // PROF: per-item phases (wave 0): {Q loads + first K / V tiles landed, first tile's S / reference / softmax / step 1, wait for the refills, steady loop, drain, epilogue, items}
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t = 0;      // PROF: per-item phases (wave 0): {Q loads + first K / V tiles landed, first tile's S / reference / softmax / step 1, wait for the refills, steady loop, drain, epilogue, items}
     unsigned long long pf_fence = 0, pf_a = 0, pf_b = 0, pf_n = 0;      // PROF: the steady loop's per-tile parts, summed over the items (stored once, at the end: an atomic per item would sit in the drain's vmcnt wait)
     while (item < item_end) {
     if (ticketed && tid == 0) next_ticket = atomicAdd(tickets, 1u);      // the item after this one; the answer has 2.8 ms to arrive
@@ -823,7 +823,7 @@ __global__ __launch_bounds__(M16_THREADS, 1) void attn_hd128_m16_kernel(
             }
         }
     }
-    if (PROF) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const unsigned long long tt = __builtin_amdgcn_s_memtime(); ph[5] += tt - ph_t; ph[6] += 1; }      // (PROF waits for the stores: what the next item's loads queue behind)
+    if (PROF) { ph[7] += __builtin_amdgcn_s_memtime() - ph_t; asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const unsigned long long tt = __builtin_amdgcn_s_memtime(); ph[5] += tt - ph_t; ph[6] += 1; }      // ([7]: up to the last store's ISSUE)      // (PROF waits for the stores: what the next item's loads queue behind)
     if (ticketed) {
         if (tid == 0) s_next_item = nwg + (int)next_ticket;
         __syncthreads();
@@ -845,7 +845,7 @@ __global__ __launch_bounds__(M16_THREADS, 1) void attn_hd128_m16_kernel(
     }
     if (PROF && prof && tid == 0) {     // [1040 .. 1047): wave 0's per-item phases, summed over the workgroups and launches
 #pragma unroll
-        for (int i = 0; i < 7; ++i) atomicAdd(prof + 1040 + i, ph[i]);
+        for (int i = 0; i < 8; ++i) atomicAdd(prof + 1040 + i, ph[i]);
     }
 }
 

@@ -709,13 +709,13 @@ int main(int argc, char** argv) {
             }
         }
         {   // m16: wave 0's per-item phases (s_memtime cycles), summed over workgroups and launches
-            unsigned long long ph[7];
+            unsigned long long ph[8];
             CK(hipMemcpy(ph, buf + 1040, sizeof ph, hipMemcpyDeviceToHost));
             if (ph[6]) {
                 const double n = (double)ph[6];
                 printf("per item (%.0f items), cycles: Q + first K / V tiles landed %.0f | first tile: S, reference, softmax, step 1 %.0f | wait for the refills %.0f | steady loop %.0f | "
-                       "drain + row sums %.0f | normalise + store O, stores drained %.0f | sum %.0f\n",
-                       n, ph[0] / n, ph[1] / n, ph[2] / n, ph[3] / n, ph[4] / n, ph[5] / n, (ph[0] + ph[1] + ph[2] + ph[3] + ph[4] + ph[5]) / n);
+                       "drain + row sums %.0f | normalise + store O, stores drained %.0f (the last store issued after %.0f) | sum %.0f\n",
+                       n, ph[0] / n, ph[1] / n, ph[2] / n, ph[3] / n, ph[4] / n, ph[5] / n, ph[7] / n, (ph[0] + ph[1] + ph[2] + ph[3] + ph[4] + ph[5]) / n);
             }
         }
         mg_attn_w64_profile(nullptr);
