@@ -11,7 +11,7 @@ fi
 python __graft_entry__.py smoke > gpurun_out/${TAG}_smoke.log 2>&1
 python bench.py --workload $WL --steps ${BENCH_STEPS:-2} --warmup 1 > gpurun_out/${TAG}_bench${WL}.json.log 2>&1
 cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_prof -o bench -- python $R/bench.py --workload $WL --steps 1 --warmup 1 --no-cpu-baseline --no-pmc --no-calibration > $R/gpurun_out/${TAG}_bench${WL}_prof.log 2>&1
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_prof -o bench -- python $R/bench.py --workload $WL --steps 1 --warmup 1 --no-cpu-baseline --no-pmc --no-calibration --no-shared-prefix-leg > $R/gpurun_out/${TAG}_bench${WL}_prof.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_pmc_fetch -o f -- python $R/bench.py --workload $WL --layers 4 --steps 1 --warmup 0 --no-cpu-baseline --no-video-tail --no-pmc > $R/gpurun_out/${TAG}_pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_pmc_write -o w -- python $R/bench.py --workload $WL --layers 4 --steps 1 --warmup 0 --no-cpu-baseline --no-video-tail --no-pmc > $R/gpurun_out/${TAG}_pmc_write.log 2>&1
 cd $R
