@@ -82,7 +82,7 @@ with lib.ab_library() as h:
         def attn():
             ops.attention_hd128(q, kp, vp, o, L, heads, 1.0, prescaled=True)
         ops.pack_kv(k, v, heads, kp, vp)
-        loop('attention m16, shipped (placement 1, tickets), random operands', attn, fl)
+        loop('attention m16, shipped (placement 1's gaps, MFMAs in quads, tickets), random operands', attn, fl)
         for name, dbg in (('placement 0 (round-4 order)', 12), ('placement 2', 4), ('placement 3', 6), ('placement 4', 8), ('placement 5', 10),
                           ('shipped placement, STATIC per-XCD partition', 16)):
             h.mg_attn_w64_debug(dbg)
